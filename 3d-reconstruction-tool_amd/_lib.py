@@ -1,0 +1,85 @@
+"""ctypes binding of libamvs.so (the C ABI declared in include/amvs.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+present, loading / context creation raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamvs.so")
+
+AMVS_MAX_SRC = 6
+SUPPORTED_PATCH_SIZES = (5, 7, 11)
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int)
+
+
+class PmParams(C.Structure):
+    _fields_ = [("patch_size", C.c_int32), ("num_iterations", C.c_int32),
+                ("num_samples", C.c_int32), ("tile_rows", C.c_int32),
+                ("depth_min", C.c_float), ("depth_max", C.c_float),
+                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("confidence_ms", C.c_double),
+                ("sweep_launches", C.c_int64), ("pixel_hypotheses", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/amvs.h declares
+SIGNATURES = {
+    "amvs_version": (C.c_char_p, []),
+    "amvs_last_error": (C.c_char_p, [C.c_void_p]),
+    "amvs_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p, C.POINTER(C.c_void_p)]),
+    "amvs_destroy": (C.c_int, [C.c_void_p]),
+    "amvs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "amvs_sync": (C.c_int, [C.c_void_p]),
+    "amvs_set_view": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p, f32p]),
+    "amvs_set_view_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, f32p, f32p]),
+    "amvs_patchmatch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(PmParams),
+                                  C.c_uint64, f32p, f32p, f32p]),
+    "amvs_patchmatch_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int,
+                                         C.POINTER(PmParams), C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amvs_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,
+                                   C.c_float, f32p, f32p]),
+    "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,
+                                          C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "amvs_eval_cost": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_confidence": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_propagate_step": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p, f32p,
+                                      C.c_int, C.c_int, C.c_float]),
+    "amvs_refine_step": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p, f32p,
+                                   C.c_uint64, C.c_uint32, C.c_uint32,
+                                   C.c_float, C.c_float, C.c_float, C.c_float]),
+    "amvs_init_state": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_float,
+                                  f32p, f32p, f32p]),
+    "amvs_box_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_rng_fill": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, f32p, f32p]),
+}
+
+_lib = None
+
+
+class AmvsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libamvs.so and bind every declared entry point (raises if absent)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmvsError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                "(or `make -C 3d-reconstruction-tool_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,248 @@
+"""PatchMatch multi-view stereo: host side of the MI355X backend.
+
+Mirrors the call surface of the reference's src/core/mvs_patchmatch.py
+(`PatchMatchMVS(camera, scale, patch_size, num_iterations, num_samples, min_views,
+depth_min, depth_max).reconstruct(images, poses, sparse_points) -> (points, colors)`,
+reference :43-50, :72-74) so `run_reconstruction.py --mvs` can import this class
+instead.  The per-pixel sweep (`_patchmatch_cuda`, reference :225-321) runs in the
+gfx950 kernels behind libamvs.so; everything kept here is the small float64 host
+geometry around it (depth range :141-165, source selection :193-223, fusion :536-570,
+filtering :572-588).
+
+Differences a caller can observe, all opt-in or performance-only:
+  * every view is uploaded once and all reference views are swept in batches
+    (the reference re-uploads per view and loops serially, :104-123, :235-257);
+  * `seed` names the RNG streams (the reference is unseeded);
+  * under an initialised torch.distributed process group the reference views are
+    sharded over ranks and the per-view maps are all-gathered (see ..parallel).
+"""
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .camera import Camera, CameraPose
+from .imageprep import prepare_view
+from .. import engine as _engine
+from .. import parallel as _parallel
+
+
+@dataclass
+class DepthNormalMap:
+    """Per-view result (reference :30-35)."""
+    depth: np.ndarray       # (H, W) float32
+    normal: np.ndarray      # (H, W, 3) float32
+    confidence: np.ndarray  # (H, W) float32, number of photo-consistent source views
+
+
+class PatchMatchMVS:
+    NUM_SOURCES = 4          # reference :108
+
+    def __init__(self, camera: Camera, scale: float = 0.25, patch_size: int = 11,
+                 num_iterations: int = 3, num_samples: int = 8, min_views: int = 3,
+                 depth_min: float = 0.1, depth_max: float = 100.0, *,
+                 seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
+                 process_group=None):
+        self.camera = camera
+        self.scale = scale
+        self.patch_size = patch_size
+        self.num_iterations = num_iterations
+        self.num_samples = num_samples
+        self.min_views = min_views
+        self.depth_min = depth_min
+        self.depth_max = depth_max
+        self.seed = seed
+        self.views_per_batch = max(1, int(views_per_batch))
+        self.process_group = process_group
+        self.device_id = _parallel.local_device() if device is None else int(device)
+        print(f"PatchMatch MVS using GPU: HIP device {self.device_id} (gfx950 kernels)")
+        # scaled intrinsics: first two rows times `scale` (reference :69-70)
+        self.K_scaled = camera.K.copy()
+        self.K_scaled[:2] *= scale
+        self._engine = None
+        self._engine_key = None
+        self._slot = {}
+        self.last_timing = None
+
+    # ------------------------------------------------------------------ public ----
+    def reconstruct(self, images: List[dict], poses: Dict[int, CameraPose],
+                    sparse_points: np.ndarray = None) -> Tuple[np.ndarray, np.ndarray]:
+        print("\n" + "=" * 60)
+        print("PATCHMATCH MULTI-VIEW STEREO")
+        print(f"  Scale: {self.scale}x, Patch: {self.patch_size}, Iters: {self.num_iterations}")
+        print("=" * 60)
+        t0 = time.time()
+        cam_indices = sorted(poses.keys())
+        n_cams = len(cam_indices)
+        if n_cams < 3:                                   # reference :88-90
+            print("Need at least 3 cameras")
+            return np.array([]), np.array([])
+
+        self._estimate_depth_range(poses, sparse_points)
+        print(f"  Depth range: [{self.depth_min:.2f}, {self.depth_max:.2f}]")
+        print("\nPreparing images...")
+        proc_images = self._prepare_images(images, cam_indices)
+
+        print(f"\nComputing depth maps for {n_cams} views...")
+        jobs = []
+        for ref_idx in cam_indices:
+            src = self._select_source_views(ref_idx, cam_indices, poses, k=self.NUM_SOURCES)
+            if len(src) < 2:                             # reference :110-112
+                print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: skipped (not enough neighbors)")
+                continue
+            jobs.append((ref_idx, src))
+
+        depth_maps = self._sweep(jobs, proc_images, poses, cam_indices)
+
+        print("\nFusing depth maps...")
+        points, colors = self._fuse_depth_maps(depth_maps, proc_images, poses)
+        print(f"  Raw points: {len(points):,}")
+        if len(points) > 0:
+            points, colors = self._filter_points(points, colors)
+            print(f"  After filtering: {len(points):,}")
+        print(f"\nPatchMatch MVS completed in {time.time() - t0:.1f}s")
+        return points, colors
+
+    # ------------------------------------------------------------- host geometry --
+    def _estimate_depth_range(self, poses: Dict[int, CameraPose], sparse_points: np.ndarray = None):
+        """1st / 99th*1.5 percentile of positive sparse-point depths over all cameras, else a
+        camera-spread fallback (reference :141-165)."""
+        centers = np.array([poses[i].center for i in poses])
+        if sparse_points is not None and len(sparse_points) > 0:
+            pooled = []
+            for idx in poses:
+                z = poses[idx].transform_points(sparse_points)[:, 2]
+                z = z[z > 0]
+                if z.size:
+                    pooled.extend(z)
+            if pooled:
+                self.depth_min = max(0.1, np.percentile(pooled, 1))
+                self.depth_max = np.percentile(pooled, 99) * 1.5
+                return
+        spread = np.linalg.norm(centers - np.median(centers, axis=0), axis=1)
+        scene_scale = np.percentile(spread, 90)
+        self.depth_min = max(0.1, scene_scale * 0.05)
+        self.depth_max = scene_scale * 10.0
+
+    def _prepare_images(self, images: List[dict], indices: List[int]) -> Dict:
+        """Scaled colour + float32 gray in [0,1] per view (reference :167-191; the Sobel
+        gradients computed there are never read and are not produced here)."""
+        return {idx: prepare_view(images[idx]["image"], self.scale) for idx in indices}
+
+    def _select_source_views(self, ref_idx: int, all_indices: List[int],
+                             poses: Dict[int, CameraPose], k: int = 4) -> List[int]:
+        """Score = baseline * (1 - |angle-20|/60) for 5 < angle < 60 degrees, else 0; the k best
+        in stable descending order (reference :193-223)."""
+        c_ref = poses[ref_idx].center
+        z_ref = poses[ref_idx].R[2, :]
+        scored = []
+        for idx in all_indices:
+            if idx == ref_idx:
+                continue
+            baseline = np.linalg.norm(poses[idx].center - c_ref)
+            cosang = np.clip(np.dot(z_ref, poses[idx].R[2, :]), -1, 1)
+            angle = np.degrees(np.arccos(cosang))
+            score = baseline * (1 - abs(angle - 20) / 60) if 5 < angle < 60 else 0
+            scored.append((idx, score))
+        scored.sort(key=lambda item: item[1], reverse=True)
+        return [idx for idx, _ in scored[:k]]
+
+    # ----------------------------------------------------------------- device -----
+    def _pm_params(self):
+        return _engine.make_pm_params(self.patch_size, self.num_iterations, self.num_samples,
+                                      self.depth_min, self.depth_max)
+
+    def _ensure_engine(self, images: Dict, poses: Dict[int, CameraPose], indices: List[int]):
+        """Upload every view once; cached while the same prepared-image dict is in use."""
+        key = (id(images), tuple(indices))
+        if self._engine is not None and self._engine_key == key:
+            return self._engine
+        if self._engine is not None:
+            self._engine.close()
+        H, W = images[indices[0]]["shape"]
+        for idx in indices:
+            if tuple(images[idx]["shape"]) != (H, W):
+                raise ValueError("all views must share one processed size")
+        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id)
+        self._slot = {idx: s for s, idx in enumerate(indices)}
+        for idx in indices:
+            eng.set_view(self._slot[idx], images[idx]["gray"], poses[idx].R, poses[idx].t)
+        self._engine, self._engine_key = eng, key
+        return eng
+
+    def _run_batch(self, eng, batch):
+        """batch: list of (ref_idx, src_indices) with equal source counts -> maps per ref."""
+        refs = [self._slot[r] for r, _ in batch]
+        srcs = [[self._slot[s] for s in src] for _, src in batch]
+        depth, normal, conf = eng.patchmatch(refs, srcs, self._pm_params(), self.seed_for_stream())
+        self.last_timing = eng.timing()
+        return depth, normal, conf
+
+    def seed_for_stream(self):
+        return int(self.seed)
+
+    def _patchmatch_cuda(self, ref_idx: int, src_indices: List[int], images: Dict,
+                         poses: Dict[int, CameraPose]) -> DepthNormalMap:
+        """One reference view (reference :225-321).  RNG stream = (seed, engine slot of ref)."""
+        eng = self._ensure_engine(images, poses, sorted(images.keys()))
+        depth, normal, conf = self._run_batch(eng, [(ref_idx, list(src_indices))])
+        return DepthNormalMap(depth=depth[0], normal=normal[0], confidence=conf[0])
+
+    def _sweep(self, jobs, proc_images, poses, cam_indices) -> Dict[int, DepthNormalMap]:
+        """All reference views: sharded over ranks when torch.distributed is initialised,
+        batched per GPU, one progress line per view (reference :104-123)."""
+        n_cams = len(cam_indices)
+        rank, world = _parallel.rank_world(self.process_group)
+        mine = _parallel.shard(len(jobs), rank, world)
+        eng = self._ensure_engine(proc_images, poses, cam_indices)
+        local = {}
+        by_count = {}
+        for j in mine:
+            by_count.setdefault(len(jobs[j][1]), []).append(j)
+        for _, idxs in sorted(by_count.items()):
+            for b in range(0, len(idxs), self.views_per_batch):
+                chunk = idxs[b:b + self.views_per_batch]
+                t1 = time.time()
+                depth, normal, conf = self._run_batch(eng, [jobs[j] for j in chunk])
+                per_view = (time.time() - t1) / len(chunk)
+                for n, j in enumerate(chunk):
+                    local[j] = DepthNormalMap(depth=depth[n], normal=normal[n], confidence=conf[n])
+                    ref_idx = jobs[j][0]
+                    valid = int(np.sum(conf[n] >= self.min_views))
+                    print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: "
+                          f"{valid:,} valid pixels ({per_view:.1f}s)")
+        if world > 1:
+            local = _parallel.allgather_maps(local, len(jobs), proc_images[cam_indices[0]]["shape"],
+                                             self.process_group, DepthNormalMap)
+        return {jobs[j][0]: local[j] for j in sorted(local)}
+
+    # ------------------------------------------------------------ fusion / filter --
+    def _fuse_depth_maps(self, depth_maps: Dict[int, DepthNormalMap], images: Dict,
+                         poses: Dict[int, CameraPose]) -> Tuple[np.ndarray, np.ndarray]:
+        """Back-project pixels with confidence >= min_views to world space (reference :536-570)."""
+        K_inv = np.linalg.inv(self.K_scaled)
+        clouds, cloud_colors = [], []
+        for idx, dm in depth_maps.items():
+            keep = dm.confidence >= self.min_views
+            if not np.any(keep):
+                continue
+            ys, xs = np.where(keep)
+            pix = np.stack([xs, ys, np.ones_like(xs)], axis=-1)
+            cam_pts = (pix @ K_inv.T) * dm.depth[keep][:, np.newaxis]
+            clouds.append((cam_pts - poses[idx].t) @ poses[idx].R)
+            cloud_colors.append(images[idx]["color"][ys, xs][:, ::-1])      # BGR -> RGB
+        if not clouds:
+            return np.array([]).reshape(0, 3), np.array([]).reshape(0, 3)
+        return np.vstack(clouds), np.vstack(cloud_colors)
+
+    def _filter_points(self, points: np.ndarray, colors: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """95th-percentile radius cut around the median, then 1 cm voxel de-duplication keeping
+        the first point of every voxel in key order (reference :572-588)."""
+        dist = np.linalg.norm(points - np.median(points, axis=0), axis=1)
+        keep = dist < np.percentile(dist, 95)
+        points, colors = points[keep], colors[keep]
+        cell = np.floor(points / 0.01).astype(np.int64)
+        keys = cell[:, 0] * 1000000000 + cell[:, 1] * 1000000 + cell[:, 2]
+        _, first = np.unique(keys, return_index=True)
+        return points[first], colors[first]

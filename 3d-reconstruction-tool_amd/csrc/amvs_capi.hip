@@ -1,0 +1,678 @@
+// amvs_capi.hip -- the C ABI of include/amvs.h: context, device memory, step scheduling.
+//
+// Host-side orchestration of PatchMatchMVS._patchmatch_cuda (mvs_patchmatch.py:225-321)
+// and DenseStereoReconstructor._plane_sweep_torch (dense_stereo.py:222-316): all views of
+// a scene are uploaded once and stay resident; a batch of reference views is swept
+// together, one kernel launch per cost-evaluation step over the whole batch.
+#include "../../include/amvs.h"
+#include "amvs_kernels.h"
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static_assert(AMVS_MAX_SRC == AMVS_KMAX_SRC, "source-count limits out of sync");
+
+namespace {
+
+std::string g_create_error;
+
+struct Stats {
+    float *mean = nullptr, *var = nullptr;
+    std::vector<char> done;
+};
+
+}  // namespace
+
+struct amvs_ctx {
+    int device = 0, H = 0, W = 0, n_views = 0;
+    long long stride = 0;   // floats between images (H*W rounded up + tail padding)
+    float K[9], Kinv[9];
+    std::vector<std::array<float, 9>> R;
+    std::vector<std::array<float, 3>> t;
+    std::vector<char> have;
+    float *d_images = nullptr;
+    std::map<int, Stats> stats;
+    int cap_slots = 0;
+    float *d_depth[2] = {nullptr, nullptr}, *d_cost[2] = {nullptr, nullptr},
+          *d_normal[2] = {nullptr, nullptr}, *d_aux = nullptr;
+    amvs::Job *d_jobs = nullptr;
+    int cap_jobs = 0;
+    float *d_planes = nullptr;
+    int cap_planes = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing_pending = false;
+    amvs_timing timing{};
+    std::string err;
+};
+
+namespace {
+
+int fail(amvs_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), AMVS_EHIP,                                                   \
+                        std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+int bind_device(amvs_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return AMVS_OK;
+}
+
+int check_patch_src(amvs_ctx *c, int patch, int n_src)
+{
+    if (!amvs::patch_supported(patch))
+        return fail(c, AMVS_EUNSUPPORTED,
+                    "patch_size " + std::to_string(patch) + " not compiled in (supported: 5, 7, 11)");
+    if (n_src < 2 || n_src > AMVS_MAX_SRC)
+        return fail(c, AMVS_EUNSUPPORTED,
+                    "n_src " + std::to_string(n_src) + " outside [2, " + std::to_string(AMVS_MAX_SRC) + "]");
+    return AMVS_OK;
+}
+
+int ensure_slots(amvs_ctx *c, int n)
+{
+    if (n <= c->cap_slots) return AMVS_OK;
+    const size_t hw = (size_t)c->H * c->W;
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_depth[i]) (void)hipFree(c->d_depth[i]);
+        if (c->d_cost[i]) (void)hipFree(c->d_cost[i]);
+        if (c->d_normal[i]) (void)hipFree(c->d_normal[i]);
+        c->d_depth[i] = c->d_cost[i] = c->d_normal[i] = nullptr;
+    }
+    if (c->d_aux) (void)hipFree(c->d_aux);
+    c->d_aux = nullptr;
+    c->cap_slots = 0;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipMalloc(&c->d_depth[i], sizeof(float) * hw * n));
+        HIPCHK(c, hipMalloc(&c->d_cost[i], sizeof(float) * hw * n));
+        HIPCHK(c, hipMalloc(&c->d_normal[i], sizeof(float) * hw * n * 3));
+    }
+    HIPCHK(c, hipMalloc(&c->d_aux, sizeof(float) * hw * n));
+    c->cap_slots = n;
+    return AMVS_OK;
+}
+
+int ensure_jobs(amvs_ctx *c, int n)
+{
+    if (n <= c->cap_jobs) return AMVS_OK;
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    c->d_jobs = nullptr; c->cap_jobs = 0;
+    HIPCHK(c, hipMalloc(&c->d_jobs, sizeof(amvs::Job) * n));
+    c->cap_jobs = n;
+    return AMVS_OK;
+}
+
+// mean1 / var1 of every uploaded view for this patch size (computed once, kept resident)
+int ensure_stats(amvs_ctx *c, int patch)
+{
+    Stats &s = c->stats[patch];
+    if (!s.mean) {
+        HIPCHK(c, hipMalloc(&s.mean, sizeof(float) * c->stride * c->n_views));
+        HIPCHK(c, hipMalloc(&s.var, sizeof(float) * c->stride * c->n_views));
+        s.done.assign(c->n_views, 0);
+    }
+    for (int v = 0; v < c->n_views; ++v) {
+        if (!c->have[v] || s.done[v]) continue;
+        HIPCHK(c, amvs::launch_box_stats(patch, c->d_images, c->stride, c->H, c->W, v, 1, s.mean,
+                                         s.var, c->stream));
+        s.done[v] = 1;
+    }
+    return AMVS_OK;
+}
+
+int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src)
+{
+    if (n_ref <= 0 || !ref_ids || !src_ids) return fail(c, AMVS_EINVAL, "empty batch");
+    std::vector<amvs::Job> jobs(n_ref);
+    for (int i = 0; i < n_ref; ++i) {
+        amvs::Job &j = jobs[i];
+        std::memset(&j, 0, sizeof(j));
+        const int r = ref_ids[i];
+        if (r < 0 || r >= c->n_views || !c->have[r])
+            return fail(c, AMVS_EINVAL, "reference view " + std::to_string(r) + " not uploaded");
+        std::memcpy(j.Rref, c->R[r].data(), 36);
+        std::memcpy(j.tref, c->t[r].data(), 12);
+        j.ref_img = r;
+        j.stream_view = (uint32_t)r;
+        j.slot = i;
+        for (int s = 0; s < n_src; ++s) {
+            const int v = src_ids[i * n_src + s];
+            if (v < 0 || v >= c->n_views || !c->have[v])
+                return fail(c, AMVS_EINVAL, "source view " + std::to_string(v) + " not uploaded");
+            j.src_img[s] = v;
+            std::memcpy(j.Rs[s], c->R[v].data(), 36);
+            std::memcpy(j.ts[s], c->t[v].data(), 12);
+        }
+    }
+    int rc = ensure_jobs(c, n_ref);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, jobs.data(), sizeof(amvs::Job) * n_ref,
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // `jobs` is a stack-lifetime staging buffer
+    return AMVS_OK;
+}
+
+int pick_tile_rows(const amvs_ctx *c, int patch, int n_jobs, int requested, int cap)
+{
+    if (requested > 0) return requested < cap ? requested : cap;
+    const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
+    // tallest strip that still gives the 256 CUs several waves per SIMD
+    const int cands[4] = {64, 32, 16, 8};
+    for (int th : cands) {
+        if (th > cap) continue;
+        const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
+        if (waves >= 8192) return th;
+    }
+    return 8;
+}
+
+amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
+{
+    amvs::StepArgs a{};
+    a.H = c->H; a.W = c->W; a.TH = TH;
+    a.tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
+    a.tiles_y = (c->H + TH - 1) / TH;
+    a.n_jobs = n_jobs;
+    a.img_stride = c->stride;
+    std::memcpy(a.K, c->K, 36);
+    std::memcpy(a.Kinv, c->Kinv, 36);
+    a.images = c->d_images;
+    const Stats &s = c->stats.at(patch);
+    a.mean1 = s.mean; a.var1 = s.var;
+    a.jobs = c->d_jobs;
+    a.aux = c->d_aux;
+    return a;
+}
+
+void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur)
+{
+    a.d_in = c->d_depth[cur]; a.c_in = c->d_cost[cur]; a.n_in = c->d_normal[cur];
+    a.d_out = c->d_depth[cur ^ 1]; a.c_out = c->d_cost[cur ^ 1]; a.n_out = c->d_normal[cur ^ 1];
+}
+
+void resolve_timing(amvs_ctx *c)
+{
+    if (!c->timing_pending) return;
+    float ms0 = 0.f, ms1 = 0.f;
+    if (hipEventSynchronize(c->ev[2]) == hipSuccess) {
+        (void)hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&ms1, c->ev[1], c->ev[2]);
+    }
+    c->timing.sweep_ms = ms0;
+    c->timing.confidence_ms = ms1;
+    c->timing_pending = false;
+}
+
+// single-view, single-step helper for the test entry points
+struct OneStep {
+    amvs_ctx *c;
+    amvs::StepArgs a;
+    int patch, n_src;
+    size_t hw;
+};
+
+int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch, OneStep &o)
+{
+    if (!c) return AMVS_EINVAL;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = check_patch_src(c, patch, n_src))) return rc;
+    if ((rc = ensure_slots(c, 1))) return rc;
+    if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src))) return rc;
+    if ((rc = ensure_stats(c, patch))) return rc;
+    o.c = c; o.patch = patch; o.n_src = n_src; o.hw = (size_t)c->H * c->W;
+    o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, 1, 0, 64));
+    set_io(o.a, c, 0);
+    return AMVS_OK;
+}
+
+int upload_state(amvs_ctx *c, size_t hw, const float *depth, const float *normal, const float *cost)
+{
+    if (depth) HIPCHK(c, hipMemcpyAsync(c->d_depth[0], depth, 4 * hw, hipMemcpyHostToDevice, c->stream));
+    if (normal) HIPCHK(c, hipMemcpyAsync(c->d_normal[0], normal, 12 * hw, hipMemcpyHostToDevice, c->stream));
+    if (cost) HIPCHK(c, hipMemcpyAsync(c->d_cost[0], cost, 4 * hw, hipMemcpyHostToDevice, c->stream));
+    return AMVS_OK;
+}
+
+int download_state(amvs_ctx *c, size_t hw, int buf, float *depth, float *normal, float *cost)
+{
+    HIPCHK(c, hipMemcpyAsync(depth, c->d_depth[buf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal, c->d_normal[buf], 12 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cost, c->d_cost[buf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char *amvs_version(void) { return "amvs 0.1 (gfx950)"; }
+
+const char *amvs_last_error(const amvs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int amvs_create(int device_id, int H, int W, int n_views, const float K[9], const float K_inv[9],
+                amvs_ctx **out)
+{
+    if (!out) return fail(nullptr, AMVS_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (H < 2 || W < 2 || n_views < 1 || !K || !K_inv)
+        return fail(nullptr, AMVS_EINVAL, "bad image size / view count / intrinsics");
+    if ((long long)H * W > (1ll << 30)) return fail(nullptr, AMVS_EINVAL, "image too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, AMVS_EHIP, "no HIP device available (this backend has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, AMVS_EINVAL, "device_id out of range");
+    amvs_ctx *c = new amvs_ctx();
+    c->device = device_id; c->H = H; c->W = W; c->n_views = n_views;
+    // rows of an image are W floats; one extra 256-byte line of tail padding per image
+    c->stride = (((long long)H * W + 63) / 64) * 64 + 64;
+    std::memcpy(c->K, K, 36);
+    std::memcpy(c->Kinv, K_inv, 36);
+    c->R.resize(n_views); c->t.resize(n_views); c->have.assign(n_views, 0);
+    auto bail = [&](const char *what, hipError_t e) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        amvs_destroy(c);
+        return fail(nullptr, AMVS_EHIP, m);
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(&c->d_images, sizeof(float) * c->stride * n_views)) != hipSuccess)
+        return bail("hipMalloc(images)", e);
+    if ((e = hipMemsetAsync(c->d_images, 0, sizeof(float) * c->stride * n_views, c->stream)) != hipSuccess)
+        return bail("hipMemset(images)", e);
+    *out = c;
+    return AMVS_OK;
+}
+
+int amvs_destroy(amvs_ctx *c)
+{
+    if (!c) return AMVS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_depth[i]) (void)hipFree(c->d_depth[i]);
+        if (c->d_cost[i]) (void)hipFree(c->d_cost[i]);
+        if (c->d_normal[i]) (void)hipFree(c->d_normal[i]);
+    }
+    if (c->d_aux) (void)hipFree(c->d_aux);
+    if (c->d_jobs) (void)hipFree(c->d_jobs);
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    if (c->d_images) (void)hipFree(c->d_images);
+    for (auto &kv : c->stats) {
+        if (kv.second.mean) (void)hipFree(kv.second.mean);
+        if (kv.second.var) (void)hipFree(kv.second.var);
+    }
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return AMVS_OK;
+}
+
+int amvs_set_stream(amvs_ctx *c, void *hip_stream)
+{
+    if (!c) return AMVS_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AMVS_OK;
+}
+
+int amvs_sync(amvs_ctx *c)
+{
+    if (!c) return AMVS_EINVAL;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    return AMVS_OK;
+}
+
+static int set_view_common(amvs_ctx *c, int view, const void *gray, const float R[9], const float t[3],
+                           hipMemcpyKind kind)
+{
+    if (!c) return AMVS_EINVAL;
+    if (view < 0 || view >= c->n_views || !gray || !R || !t) return fail(c, AMVS_EINVAL, "bad view argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_images + view * c->stride, gray, sizeof(float) * c->H * c->W, kind,
+                             c->stream));
+    if (kind == hipMemcpyHostToDevice) HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(c->R[view].data(), R, 36);
+    std::memcpy(c->t[view].data(), t, 12);
+    c->have[view] = 1;
+    for (auto &kv : c->stats) if (!kv.second.done.empty()) kv.second.done[view] = 0;
+    return AMVS_OK;
+}
+
+int amvs_set_view(amvs_ctx *c, int view, const float *gray_host, const float R[9], const float t[3])
+{
+    return set_view_common(c, view, gray_host, R, t, hipMemcpyHostToDevice);
+}
+
+int amvs_set_view_device(amvs_ctx *c, int view, const void *gray_device, const float R[9], const float t[3])
+{
+    return set_view_common(c, view, gray_device, R, t, hipMemcpyDeviceToDevice);
+}
+
+int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                           const amvs_pm_params *p, uint64_t seed, void *depth_dev, void *normal_dev,
+                           void *conf_dev)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!p || !depth_dev || !normal_dev || !conf_dev) return fail(c, AMVS_EINVAL, "NULL argument");
+    if (p->num_iterations < 0 || p->num_samples < 0) return fail(c, AMVS_EINVAL, "negative iteration count");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = check_patch_src(c, p->patch_size, n_src))) return rc;
+    if ((rc = ensure_slots(c, n_ref))) return rc;
+    if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src))) return rc;
+    if ((rc = ensure_stats(c, p->patch_size))) return rc;
+
+    const size_t hw = (size_t)c->H * c->W;
+    const int TH = pick_tile_rows(c, p->patch_size, n_ref, p->tile_rows, 1 << 20);
+    amvs::StepArgs a = base_args(c, p->patch_size, n_ref, TH);
+    a.depth_min = p->depth_min; a.depth_max = p->depth_max;
+    a.seed = seed;
+    resolve_timing(c);
+    c->timing = amvs_timing{};
+
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    int cur = 0;
+    int64_t launches = 0;
+    // initialisation (mvs_patchmatch.py:268-284)
+    HIPCHK(c, amvs::launch_init(c->d_jobs, n_ref, (long long)hw, seed, p->log_depth_scale,
+                                p->log_depth_min, c->d_depth[cur], c->d_normal[cur], c->d_cost[cur],
+                                c->stream));
+    ++launches;
+    for (int it = 0; it < p->num_iterations; ++it) {
+        // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
+        // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
+        const int sgn = (it % 2 == 0) ? 1 : -1;
+        for (int k = 0; k < 2; ++k) {
+            a.mode = amvs::MODE_PROP;
+            a.oy = k == 0 ? sgn : 0;
+            a.ox = k == 0 ? 0 : sgn;
+            set_io(a, c, cur);
+            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+            cur ^= 1; ++launches;
+        }
+        // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
+        a.mode = amvs::MODE_REFINE;
+        a.depth_range = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
+        a.normal_range = (float)(0.5 * std::pow(0.5, it));
+        for (int s = 0; s < p->num_samples; ++s) {
+            a.draw = (unsigned)(1 + it * p->num_samples + s);
+            set_io(a, c, cur);
+            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+            cur ^= 1; ++launches;
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
+    a.mode = amvs::MODE_CONF;
+    set_io(a, c, cur);
+    a.aux = (float *)conf_dev;
+    HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    c->timing.sweep_launches = launches;
+    c->timing.pixel_hypotheses =
+        (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
+    c->timing_pending = true;
+    return AMVS_OK;
+}
+
+int amvs_patchmatch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                    const amvs_pm_params *p, uint64_t seed, float *depth_out, float *normal_out,
+                    float *conf_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!depth_out || !normal_out || !conf_out || n_ref <= 0) return fail(c, AMVS_EINVAL, "NULL output");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    float *dd = nullptr, *dn = nullptr, *dc = nullptr;
+    HIPCHK(c, hipMalloc(&dd, 4 * hw * n_ref));
+    hipError_t e1 = hipMalloc(&dn, 12 * hw * n_ref), e2 = hipMalloc(&dc, 4 * hw * n_ref);
+    if (e1 == hipSuccess && e2 == hipSuccess) {
+        rc = amvs_patchmatch_device(c, n_ref, ref_ids, src_ids, n_src, p, seed, dd, dn, dc);
+        if (rc == AMVS_OK) {
+            hipError_t e = hipMemcpyAsync(depth_out, dd, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(normal_out, dn, 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(conf_out, dc, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = fail(c, AMVS_EHIP, std::string("download: ") + hipGetErrorString(e));
+            resolve_timing(c);
+        }
+    } else {
+        rc = fail(c, AMVS_EHIP, "hipMalloc(outputs) failed");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (dd) (void)hipFree(dd);
+    if (dn) (void)hipFree(dn);
+    if (dc) (void)hipFree(dc);
+    return rc;
+}
+
+int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
+{
+    if (!c || !out) return AMVS_EINVAL;
+    resolve_timing(const_cast<amvs_ctx *>(c));
+    *out = c->timing;
+    return AMVS_OK;
+}
+
+int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
+                            const float *depths, int D, int patch_size, float thresh, void *depth_dev,
+                            void *conf_dev)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!depths || D < 1 || D > 65535 || !depth_dev || !conf_dev) return fail(c, AMVS_EINVAL, "bad plane list / outputs");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = check_patch_src(c, patch_size, n_nbr))) return rc;
+    if ((rc = upload_jobs(c, n_ref, ref_ids, nbr_ids, n_nbr))) return rc;
+    if ((rc = ensure_stats(c, patch_size))) return rc;
+    if (D > c->cap_planes) {
+        if (c->d_planes) (void)hipFree(c->d_planes);
+        c->d_planes = nullptr; c->cap_planes = 0;
+        HIPCHK(c, hipMalloc(&c->d_planes, sizeof(float) * D));
+        c->cap_planes = D;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_planes, depths, sizeof(float) * D, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    amvs::SweepArgs a{};
+    a.H = c->H; a.W = c->W;
+    a.TH = pick_tile_rows(c, patch_size, n_ref, 0, AMVS_SWEEP_MAX_TH);
+    a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
+    a.tiles_y = (c->H + a.TH - 1) / a.TH;
+    a.n_jobs = n_ref; a.D = D;
+    a.img_stride = c->stride;
+    std::memcpy(a.K, c->K, 36);
+    std::memcpy(a.Kinv, c->Kinv, 36);
+    a.images = c->d_images;
+    const Stats &s = c->stats.at(patch_size);
+    a.mean1 = s.mean; a.var1 = s.var;
+    a.depths = c->d_planes;
+    a.thresh = thresh;
+    a.depth_out = (float *)depth_dev; a.conf_out = (float *)conf_dev;
+    a.jobs = c->d_jobs;
+    resolve_timing(c);
+    c->timing = amvs_timing{};
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, amvs::launch_sweep(patch_size, n_nbr, a, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    c->timing.sweep_launches = 1;
+    c->timing.pixel_hypotheses = (int64_t)n_ref * c->H * c->W * D;
+    c->timing_pending = true;
+    return AMVS_OK;
+}
+
+int amvs_plane_sweep(amvs_ctx *c, int ref, const int *nbr_ids, int n_nbr, const float *depths, int D,
+                     int patch_size, float thresh, float *depth_out, float *conf_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!depth_out || !conf_out) return fail(c, AMVS_EINVAL, "NULL output");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = ensure_slots(c, 1))) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    rc = amvs_plane_sweep_device(c, 1, &ref, nbr_ids, n_nbr, depths, D, patch_size, thresh,
+                                 c->d_depth[0], c->d_aux);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(depth_out, c->d_depth[0], 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    return AMVS_OK;
+}
+
+int amvs_eval_cost(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size,
+                   const float *depth_in, float *cost_out)
+{
+    OneStep o;
+    int rc = one_step_begin(c, ref, src_ids, n_src, patch_size, o);
+    if (rc) return rc;
+    if (!depth_in || !cost_out) return fail(c, AMVS_EINVAL, "NULL argument");
+    if ((rc = upload_state(c, o.hw, depth_in, nullptr, nullptr))) return rc;
+    o.a.mode = amvs::MODE_EVAL;
+    HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cost_out, c->d_aux, 4 * o.hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+int amvs_confidence(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size,
+                    const float *depth_in, float *conf_out)
+{
+    OneStep o;
+    int rc = one_step_begin(c, ref, src_ids, n_src, patch_size, o);
+    if (rc) return rc;
+    if (!depth_in || !conf_out) return fail(c, AMVS_EINVAL, "NULL argument");
+    if ((rc = upload_state(c, o.hw, depth_in, nullptr, nullptr))) return rc;
+    o.a.mode = amvs::MODE_CONF;
+    HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
+    HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * o.hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+int amvs_propagate_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size, float *depth,
+                        float *normal, float *cost, int oy, int ox, float depth_min)
+{
+    OneStep o;
+    int rc = one_step_begin(c, ref, src_ids, n_src, patch_size, o);
+    if (rc) return rc;
+    if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
+    if ((rc = upload_state(c, o.hw, depth, normal, cost))) return rc;
+    o.a.mode = amvs::MODE_PROP;
+    o.a.oy = oy; o.a.ox = ox; o.a.depth_min = depth_min;
+    HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
+    return download_state(c, o.hw, 1, depth, normal, cost);
+}
+
+int amvs_refine_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size, float *depth,
+                     float *normal, float *cost, uint64_t seed, uint32_t stream_view, uint32_t draw,
+                     float depth_range, float normal_range, float depth_min, float depth_max)
+{
+    OneStep o;
+    int rc = one_step_begin(c, ref, src_ids, n_src, patch_size, o);
+    if (rc) return rc;
+    if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
+    if ((rc = upload_state(c, o.hw, depth, normal, cost))) return rc;
+    // the job's RNG stream defaults to the reference view; tests may address another stream
+    HIPCHK(c, hipMemcpyAsync(&c->d_jobs[0].stream_view, &stream_view, sizeof(uint32_t),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    o.a.mode = amvs::MODE_REFINE;
+    o.a.seed = seed; o.a.draw = draw;
+    o.a.depth_range = depth_range; o.a.normal_range = normal_range;
+    o.a.depth_min = depth_min; o.a.depth_max = depth_max;
+    HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
+    return download_state(c, o.hw, 1, depth, normal, cost);
+}
+
+int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_depth_scale,
+                    float log_depth_min, float *depth, float *normal, float *cost)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = ensure_slots(c, 1))) return rc;
+    if ((rc = ensure_jobs(c, 1))) return rc;
+    amvs::Job j;
+    std::memset(&j, 0, sizeof(j));
+    j.stream_view = stream_view;
+    HIPCHK(c, hipMemcpyAsync(c->d_jobs, &j, sizeof(j), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, amvs::launch_init(c->d_jobs, 1, (long long)hw, seed, log_depth_scale, log_depth_min,
+                                c->d_depth[0], c->d_normal[0], c->d_cost[0], c->stream));
+    return download_state(c, hw, 0, depth, normal, cost);
+}
+
+int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float *var_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (view < 0 || view >= c->n_views || !c->have[view] || !mean_out || !var_out)
+        return fail(c, AMVS_EINVAL, "bad view / NULL output");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if (!amvs::patch_supported(patch_size)) return fail(c, AMVS_EUNSUPPORTED, "patch_size not compiled in");
+    if ((rc = ensure_stats(c, patch_size))) return rc;
+    const Stats &s = c->stats.at(patch_size);
+    const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, hipMemcpyAsync(mean_out, s.mean + view * c->stride, 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(var_out, s.var + view * c->stride, 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+int amvs_rng_fill(amvs_ctx *c, uint64_t seed, uint32_t stream_view, uint32_t draw, int64_t n, float *u_out,
+                  float *n_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (n < 0 || n > (1ll << 31)) return fail(c, AMVS_EINVAL, "bad n");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    float *du = nullptr, *dn = nullptr;
+    if (u_out) HIPCHK(c, hipMalloc(&du, 4 * (size_t)(n ? n : 1)));
+    if (n_out && hipMalloc(&dn, 12 * (size_t)(n ? n : 1)) != hipSuccess) {
+        if (du) (void)hipFree(du);
+        return fail(c, AMVS_EHIP, "hipMalloc(rng) failed");
+    }
+    hipError_t e = amvs::launch_rng_fill(seed, stream_view, draw, n, du, dn, c->stream);
+    if (e == hipSuccess && du) e = hipMemcpyAsync(u_out, du, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && dn) e = hipMemcpyAsync(n_out, dn, 12 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (du) (void)hipFree(du);
+    if (dn) (void)hipFree(dn);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("rng_fill: ") + hipGetErrorString(e));
+    return AMVS_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,213 @@
+// amvs_device.h -- device-side arithmetic shared by the gfx950 kernels.
+//
+// All float32, compiled with -ffp-contract=off: the only fused operations are the
+// explicit __builtin_fmaf calls, so results are reproducible bit for bit.
+// Reference semantics: src/core/mvs_patchmatch.py (file:line cited per function).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AMVS_WAVE 64
+#define AMVS_DEV __device__ __forceinline__
+
+namespace amvs {
+
+// ---------------------------------------------------------------- RNG ------
+// Counter-hash generator standing in for torch.rand / torch.randn
+// (mvs_patchmatch.py:271,279,280,471,475).  A "draw" gives every pixel one
+// uniform and three normals; streams are keyed by (seed, view, draw).
+AMVS_DEV uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+struct StreamKey { uint32_t k1, k2; };
+
+AMVS_DEV StreamKey stream_key(uint64_t seed, uint32_t view, uint32_t draw)
+{
+    uint32_t a = fmix32((uint32_t)seed ^ 0x9E3779B9u);
+    a = fmix32(a + view);
+    uint32_t b = fmix32((uint32_t)(seed >> 32) ^ 0x85EBCA6Bu);
+    b = fmix32(b + draw);
+    b = fmix32(b ^ a);
+    return {a, b};
+}
+
+AMVS_DEV uint32_t pixel_hash(uint32_t idx, StreamKey k) { return fmix32(fmix32(idx ^ k.k1) + k.k2); }
+
+AMVS_DEV float rng_uniform(uint32_t h0) { return (float)(h0 >> 8) * 0x1p-24f; }
+
+// ln(t) for t in [0.5, 65536): exponent split + degree-9 polynomial in (m - 1).
+AMVS_DEV float log_poly(float t)
+{
+    uint32_t u = __float_as_uint(t);
+    int e = (int)((u >> 23) & 0xFF) - 127;
+    float m = __uint_as_float((u & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = __builtin_fmaf(p, f, -1.1514610310e-1f);
+    p = __builtin_fmaf(p, f, 1.1676998740e-1f);
+    p = __builtin_fmaf(p, f, -1.2420140846e-1f);
+    p = __builtin_fmaf(p, f, 1.4249322787e-1f);
+    p = __builtin_fmaf(p, f, -1.6668057665e-1f);
+    p = __builtin_fmaf(p, f, 2.0000714765e-1f);
+    p = __builtin_fmaf(p, f, -2.4999993993e-1f);
+    p = __builtin_fmaf(p, f, 3.3333331174e-1f);
+    float y = (p * f) * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = f + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
+// sin / cos on [0, pi/2]: Taylor polynomials in th^2 (errors < 6e-8).
+AMVS_DEV void sincos_quadrant(float th, float &s, float &c)
+{
+    float t2 = th * th;
+    float ps = 1.6059043837e-10f;
+    ps = __builtin_fmaf(ps, t2, -2.5052108385e-8f);
+    ps = __builtin_fmaf(ps, t2, 2.7557319224e-6f);
+    ps = __builtin_fmaf(ps, t2, -1.9841269841e-4f);
+    ps = __builtin_fmaf(ps, t2, 8.3333333333e-3f);
+    ps = __builtin_fmaf(ps, t2, -1.6666666667e-1f);
+    s = __builtin_fmaf(ps * t2, th, th);
+    float pc = 2.0876756988e-9f;
+    pc = __builtin_fmaf(pc, t2, -2.7557319224e-7f);
+    pc = __builtin_fmaf(pc, t2, 2.4801587302e-5f);
+    pc = __builtin_fmaf(pc, t2, -1.3888888889e-3f);
+    pc = __builtin_fmaf(pc, t2, 4.1666666667e-2f);
+    pc = __builtin_fmaf(pc, t2, -0.5f);
+    c = __builtin_fmaf(pc, t2, 1.0f);
+}
+
+// Box-Muller pair from one word: 16-bit radius index, 16-bit angle.
+AMVS_DEV void normal_pair(uint32_t w, float &n0, float &n1)
+{
+    uint32_t a = w >> 16, b = w & 0xFFFFu;
+    float t = (float)a + 0.5f;
+    float lnu = log_poly(t) + (-11.090354888959125f);
+    float r = __builtin_sqrtf(-2.0f * lnu);
+    uint32_t q = b >> 14;
+    float th = ((float)(b & 0x3FFFu) * 0x1p-14f) * 1.57079632679489662f;
+    float s, c;
+    sincos_quadrant(th, s, c);
+    float cs = (q & 1u) ? s : c;
+    float sn = (q & 1u) ? c : s;
+    cs = (q == 1u || q == 2u) ? -cs : cs;
+    sn = (q >= 2u) ? -sn : sn;
+    n0 = r * cs; n1 = r * sn;
+}
+
+AMVS_DEV void rng_normals3(uint32_t h0, float &n0, float &n1, float &n2)
+{
+    float spare;
+    normal_pair(fmix32(h0 + 0x9E3779B9u), n0, n1);
+    normal_pair(fmix32(h0 + 0x3C6EF372u), n2, spare);
+}
+
+// exp for the log-uniform depth initialisation (mvs_patchmatch.py:270-272).
+AMVS_DEV float exp_poly(float x)
+{
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, r * r, r) + 1.0f;
+    int ni = (int)n;
+    ni = ni > 127 ? 127 : ni;
+    ni = ni < -126 ? -126 : ni;
+    return y * __uint_as_float((uint32_t)(ni + 127) << 23);
+}
+
+// F.normalize(v, dim=-1) = v / max(||v||, 1e-12)   (mvs_patchmatch.py:281,476)
+AMVS_DEV void normalize3(float &x, float &y, float &z)
+{
+    float n = __builtin_sqrtf(x * x + y * y + z * z);
+    float d = n > 1e-12f ? n : 1e-12f;
+    x = x / d; y = y / d; z = z / d;
+}
+
+// ------------------------------------------------------------ geometry -----
+struct Mat3 { float m[9]; };
+struct Vec3 { float x, y, z; };
+
+// rays = [x,y,1] @ K_inv.T ; X = rays * d ; Xw = (X - t_ref) @ R_ref
+// (mvs_patchmatch.py:341-347).  3-term sums are fma(a2,b2,fma(a1,b1,a0*b0)).
+AMVS_DEV Vec3 backproject(const float *Kinv, const float *Rref, const float *tref,
+                          int x, int y, float d)
+{
+    float px = (float)x, py = (float)y;
+    float q0 = __builtin_fmaf(1.0f, Kinv[2], __builtin_fmaf(py, Kinv[1], px * Kinv[0])) * d - tref[0];
+    float q1 = __builtin_fmaf(1.0f, Kinv[5], __builtin_fmaf(py, Kinv[4], px * Kinv[3])) * d - tref[1];
+    float q2 = __builtin_fmaf(1.0f, Kinv[8], __builtin_fmaf(py, Kinv[7], px * Kinv[6])) * d - tref[2];
+    Vec3 w;
+    w.x = __builtin_fmaf(q2, Rref[6], __builtin_fmaf(q1, Rref[3], q0 * Rref[0]));
+    w.y = __builtin_fmaf(q2, Rref[7], __builtin_fmaf(q1, Rref[4], q0 * Rref[1]));
+    w.z = __builtin_fmaf(q2, Rref[8], __builtin_fmaf(q1, Rref[5], q0 * Rref[2]));
+    return w;
+}
+
+// Project a world point into a source view and sample it bilinearly
+// (mvs_patchmatch.py:351-377: project, bounds test, grid_sample bilinear /
+// zeros / align_corners=True).  The projection is valid when z > 0.1 and
+// lo <= u < hix, lo <= v < hiy (patch bounds :362-363, image bounds :516-517, or
+// -inf/+inf for the plane sweep, which only tests z: dense_stereo.py:280,303).
+// `live` masks lanes whose pixel is outside the image: they issue no loads and
+// return 0 (the zero padding of the box filter).
+AMVS_DEV float project_sample(const float *K, const float *Rs, const float *ts,
+                              const float *__restrict__ img, int H, int W,
+                              float lo, float hix, float hiy,
+                              Vec3 Pw, bool live, bool &valid)
+{
+    float p0 = __builtin_fmaf(Pw.z, Rs[2], __builtin_fmaf(Pw.y, Rs[1], Pw.x * Rs[0])) + ts[0];
+    float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
+    float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
+    float zz = z + 1e-8f;
+    float a = p0 / zz, b = p1 / zz;
+    float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
+    float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];
+    valid = (z > 0.1f) && (u >= lo) && (u < hix) && (v >= lo) && (v < hiy);
+    const float fw = (float)(W - 1), fh = (float)(H - 1);
+    float gx = (2.0f * u) / fw - 1.0f;
+    float gy = (2.0f * v) / fh - 1.0f;
+    float ux = (gx + 1.0f) * (fw * 0.5f);
+    float uy = (gy + 1.0f) * (fh * 0.5f);
+    float x0 = __builtin_floorf(ux), y0 = __builtin_floorf(uy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
+    float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
+    bool x0ok = (x0 >= 0.0f) && (x0 <= fw), x1ok = (x1 >= 0.0f) && (x1 <= fw);
+    bool y0ok = (y0 >= 0.0f) && (y0 <= fh), y1ok = (y1 >= 0.0f) && (y1 <= fh);
+    // clamped integer coordinates keep every issued load inside the image
+    int ix0 = min(max((int)x0, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
+    int iy0 = min(max((int)y0, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
+    float t00 = 0.0f, t01 = 0.0f, t10 = 0.0f, t11 = 0.0f;
+    if (live) {
+        t00 = img[iy0 * W + ix0]; t01 = img[iy0 * W + ix1];
+        t10 = img[iy1 * W + ix0]; t11 = img[iy1 * W + ix1];
+    }
+    t00 = (x0ok && y0ok) ? t00 : 0.0f;
+    t01 = (x1ok && y0ok) ? t01 : 0.0f;
+    t10 = (x0ok && y1ok) ? t10 : 0.0f;
+    t11 = (x1ok && y1ok) ? t11 : 0.0f;
+    float r = __builtin_fmaf(t11, se, __builtin_fmaf(t10, sw, __builtin_fmaf(t01, ne, t00 * nw)));
+    return live ? r : 0.0f;
+}
+
+// lane i <- lane i+1 (whole-wave shift; lane 63 receives 0).  hipcc folds this
+// into the consuming VALU op as `v_add_f32_dpp ... wave_shl:1`.
+AMVS_DEV float wave_shl1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));
+}
+
+}  // namespace amvs

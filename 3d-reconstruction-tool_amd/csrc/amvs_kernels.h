@@ -1,0 +1,62 @@
+// amvs_kernels.h -- host-visible launch interface of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AMVS_KMAX_SRC 6
+#define AMVS_SWEEP_MAX_TH 32
+
+namespace amvs {
+
+// One reference view of a batch: its pose, its source views and where its state lives.
+struct Job {
+    float Rref[9], tref[3];
+    float Rs[AMVS_KMAX_SRC][9], ts[AMVS_KMAX_SRC][3];
+    int ref_img;
+    int src_img[AMVS_KMAX_SRC];
+    uint32_t stream_view;   // RNG stream id (the reference view's index)
+    int slot;               // state / output slot inside the batch buffers
+};
+
+enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };
+
+struct StepArgs {
+    int H, W, TH, tiles_x, tiles_y, n_jobs;
+    long long img_stride;                    // floats between consecutive images
+    float K[9], Kinv[9];
+    const float *images, *mean1, *var1;      // [n_views][img_stride]
+    const float *d_in, *c_in, *n_in;         // state read   [slot][H*W], normals [slot][H*W*3]
+    float *d_out, *c_out, *n_out;            // state written
+    float *aux;                              // MODE_EVAL: cost map, MODE_CONF: confidence
+    const Job *jobs;
+    int mode, oy, ox;
+    float depth_min, depth_max, depth_range, normal_range;
+    unsigned long long seed;
+    unsigned draw;
+};
+
+struct SweepArgs {
+    int H, W, TH, tiles_x, tiles_y, n_jobs, D;
+    long long img_stride;
+    float K[9], Kinv[9];
+    const float *images, *mean1, *var1;
+    const float *depths;                     // [D] device
+    float thresh;
+    float *depth_out, *conf_out;             // [slot][H*W]
+    const Job *jobs;
+};
+
+bool patch_supported(int K);
+int strip_out_width(int K);
+hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
+hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
+hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
+                            int first_img, int n_img, float *mean_out, float *var_out,
+                            hipStream_t st);
+hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,
+                       float log_scale, float log_min, float *depth, float *normal, float *cost,
+                       hipStream_t st);
+hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw, long long n,
+                           float *u_out, float *n_out, hipStream_t st);
+
+}  // namespace amvs

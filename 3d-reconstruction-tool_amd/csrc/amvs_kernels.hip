@@ -1,0 +1,579 @@
+// amvs_kernels.hip -- hand-written gfx950 kernels of the PatchMatch-MVS sweep and the
+// plane-sweep stereo (reference: src/core/mvs_patchmatch.py, src/core/dense_stereo.py).
+//
+// Execution shape (CDNA4, wave64):
+//   * one 64-lane wave owns a column strip: lane i <-> image column xbase+i, and walks
+//     TH + 2*(k/2) image rows top to bottom.  Every global access of a row is one
+//     coalesced 256-byte segment (depth, cost, ref gray) or a 768-byte one (normals).
+//   * the k x k NCC window sums are separable: the vertical part lives in a per-lane
+//     register ring of the last k sampled values (no LDS, no barriers), the horizontal
+//     part is a chain of k-1 `v_add_f32_dpp ... wave_shl:1` whole-wave shifts
+//     (one VALU instruction per tap).  A strip therefore yields 64 - 2*(k/2) output
+//     columns per row.
+//   * reference semantics need the sampled value of EVERY pixel of the window at that
+//     pixel's OWN candidate depth (mvs_patchmatch.py:341-380), so halo pixels recompute
+//     their candidate: neighbour pull for propagation, counter-hash RNG for refinement.
+//   * state is ping-ponged (Jacobi semantics of mvs_patchmatch.py:429-455): a step reads
+//     buffers "in" and writes buffers "out", so strips never see half-updated maps.
+//   * block index -> strip mapping is XCD-aware: each of the 8 XCDs receives a contiguous
+//     range of strips so halos and source-image rows are shared in that XCD's L2.
+#include "amvs_kernels.h"
+#include "amvs_device.h"
+
+namespace amvs {
+
+// contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
+AMVS_DEV int xcd_remap(int bid, int nblk)
+{
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------ sweep step ---
+// One cost evaluation + select over a batch of reference views
+// (_compute_patch_cost / _spatial_propagation / _random_refinement /
+//  _compute_confidence, mvs_patchmatch.py:323-534).
+template <int K, int S>
+__global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
+{
+    constexpr int HALF = K / 2;
+    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
+    constexpr float INV_AREA = 1.0f / (float)(K * K);
+
+    const int lane = threadIdx.x;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_per_job = a.tiles_x * a.tiles_y;
+    const int job_id = t / tiles_per_job;
+    const int rem = t - job_id * tiles_per_job;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+
+    const Job &job = a.jobs[job_id];
+    const int H = a.H, W = a.W, mode = a.mode;
+    const long long HW = (long long)H * W;
+
+    const float *__restrict__ ref = a.images + job.ref_img * a.img_stride;
+    const float *__restrict__ mean1 = a.mean1 + job.ref_img * a.img_stride;
+    const float *__restrict__ var1 = a.var1 + job.ref_img * a.img_stride;
+    const float *__restrict__ d_in = a.d_in + job.slot * HW;
+    const float *__restrict__ c_in = a.c_in + job.slot * HW;
+    const float *__restrict__ n_in = a.n_in + job.slot * HW * 3;
+    float *__restrict__ d_out = a.d_out + job.slot * HW;
+    float *__restrict__ c_out = a.c_out + job.slot * HW;
+    float *__restrict__ n_out = a.n_out + job.slot * HW * 3;
+    float *__restrict__ aux = a.aux + job.slot * HW;
+
+    const StreamKey key = stream_key(a.seed, job.stream_view, a.draw);
+
+    // validity window of the projection: patch bounds (mvs_patchmatch.py:362-363) or
+    // image bounds for the confidence pass (:516-517)
+    const float lo = mode == MODE_CONF ? 0.0f : (float)HALF;
+    const float hix = mode == MODE_CONF ? (float)W : (float)(W - HALF);
+    const float hiy = mode == MODE_CONF ? (float)H : (float)(H - HALF);
+
+    const int xbase = tx * OUTW - HALF;
+    const int y0 = ty * a.TH;
+    const int xr = xbase + lane;
+    const bool col_in = (unsigned)xr < (unsigned)W;
+    const int rows = min(a.TH, H - y0) + 2 * HALF;
+
+    float ring_r[K];
+    float ring_v[S][K];
+    unsigned hist_ok[HALF + 1];
+    uint32_t hist_h0[HALF + 1];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        ring_r[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) ring_v[s][i] = 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i <= HALF; ++i) { hist_ok[i] = 0u; hist_h0[i] = 0u; }
+
+    for (int r = 0; r < rows; ++r) {
+        const int yr = y0 - HALF + r;
+        const bool live = col_in && (unsigned)yr < (unsigned)H;
+        const int pix = yr * W + xr;
+
+        // ---- candidate depth of this (possibly halo) pixel ----
+        float dc = 1.0f;
+        uint32_t h0 = 0u;
+        if (live) {
+            if (mode == MODE_PROP) {
+                // pull from (y+oy, x+ox); outside the image the candidate is depth_min
+                // (F.pad value, mvs_patchmatch.py:431-441)
+                const int ny = yr + a.oy, nx = xr + a.ox;
+                const bool inb = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
+                dc = a.depth_min;
+                if (inb) dc = d_in[ny * W + nx];
+            } else {
+                dc = d_in[pix];
+                if (mode == MODE_REFINE) {
+                    // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
+                    h0 = pixel_hash((uint32_t)pix, key);
+                    float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
+                    float d = dc + delta;
+                    d = d < a.depth_min ? a.depth_min : d;
+                    d = d > a.depth_max ? a.depth_max : d;
+                    dc = d;
+                }
+            }
+        }
+        const float rv = live ? ref[pix] : 0.0f;
+        const Vec3 Pw = backproject(a.Kinv, job.Rref, job.tref, xr, yr, dc);
+
+        unsigned okbits = 0u;
+        float v[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            bool ok;
+            v[s] = project_sample(a.K, job.Rs[s], job.ts[s],
+                                  a.images + job.src_img[s] * a.img_stride, H, W,
+                                  lo, hix, hiy, Pw, live, ok);
+            okbits |= ok ? (1u << s) : 0u;
+        }
+
+        // ---- push into the vertical rings ----
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            ring_r[i] = ring_r[i + 1];
+#pragma unroll
+            for (int s = 0; s < S; ++s) ring_v[s][i] = ring_v[s][i + 1];
+        }
+        ring_r[K - 1] = rv;
+#pragma unroll
+        for (int s = 0; s < S; ++s) ring_v[s][K - 1] = v[s];
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) { hist_ok[i] = hist_ok[i + 1]; hist_h0[i] = hist_h0[i + 1]; }
+        hist_ok[HALF] = okbits;
+        hist_h0[HALF] = h0;
+
+        if (r < 2 * HALF) continue;
+
+        // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
+        const int yc = yr - HALF;
+        const int xc = xr + HALF;
+        const bool outl = lane < OUTW && xc < W;
+        const int pc = yc * W + xc;
+        // the centre pixel was sampled by lane+HALF, HALF rows ago
+        const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
+        const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
+        float m1 = 0.0f, v1 = 0.0f;
+        if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
+
+        float total = 0.0f, cnt = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // column sums top -> bottom (plain sum; fma chains for the products)
+            float cv = ring_v[s][0];
+            float cvv = ring_v[s][0] * ring_v[s][0];
+            float crv = ring_r[0] * ring_v[s][0];
+#pragma unroll
+            for (int i = 1; i < K; ++i) {
+                cv = cv + ring_v[s][i];
+                cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
+                crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
+            }
+            // row sums right -> left: a_j(i) = a_{j-1}(i+1) + c(i)
+            float bv = cv, bvv = cvv, brv = crv;
+#pragma unroll
+            for (int j = 1; j < K; ++j) {
+                bv = wave_shl1(bv) + cv;
+                bvv = wave_shl1(bvv) + cvv;
+                brv = wave_shl1(brv) + crv;
+            }
+            // _ncc_cost (mvs_patchmatch.py:403-411)
+            const float mean2 = bv * INV_AREA;
+            const float var2 = bvv * INV_AREA - mean2 * mean2;
+            const float cov = brv * INV_AREA - m1 * mean2;
+            const float ncc = cov / (__builtin_sqrtf(v1 * var2) + 1e-8f);
+            const float cost = 1.0f - ncc;
+            const bool oks = (okc >> s) & 1u;
+            if (mode == MODE_CONF) {
+                // consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
+                const float ncc2 = 1.0f - cost;
+                if (oks && ncc2 > 0.6f) cnt += 1.0f;
+            } else if (oks) {                      // :383-384
+                total = total + cost;
+                cnt += 1.0f;
+            }
+        }
+        if (!outl) continue;
+
+        if (mode == MODE_CONF) { aux[pc] = cnt; continue; }
+
+        // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
+        const float avg = total / (cnt + 1e-8f);
+        const float newc = cnt >= 2.0f ? avg : __builtin_inff();
+        if (mode == MODE_EVAL) { aux[pc] = newc; continue; }
+
+        // ---- select (mvs_patchmatch.py:452-455 / :486-489) ----
+        const float oldd = d_in[pc];
+        const float oldc = c_in[pc];
+        float nx0 = n_in[3 * pc], nx1 = n_in[3 * pc + 1], nx2 = n_in[3 * pc + 2];
+        float candd, cn0, cn1, cn2;
+        if (mode == MODE_PROP) {
+            const int ny = yc + a.oy, nx = xc + a.ox;
+            const bool inb = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
+            candd = a.depth_min; cn0 = 0.0f; cn1 = 0.0f; cn2 = 0.0f;    // zero-padded normal
+            if (inb) {
+                const int pn = ny * W + nx;
+                candd = d_in[pn];
+                cn0 = n_in[3 * pn]; cn1 = n_in[3 * pn + 1]; cn2 = n_in[3 * pn + 2];
+            }
+        } else {
+            float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
+            float d = oldd + delta;
+            d = d < a.depth_min ? a.depth_min : d;
+            d = d > a.depth_max ? a.depth_max : d;
+            candd = d;
+            // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476)
+            float g0, g1, g2;
+            rng_normals3(h0c, g0, g1, g2);
+            cn0 = nx0 + g0 * a.normal_range;
+            cn1 = nx1 + g1 * a.normal_range;
+            cn2 = nx2 + g2 * a.normal_range;
+            normalize3(cn0, cn1, cn2);
+        }
+        const bool better = newc < oldc;
+        d_out[pc] = better ? candd : oldd;
+        c_out[pc] = better ? newc : oldc;
+        n_out[3 * pc] = better ? cn0 : nx0;
+        n_out[3 * pc + 1] = better ? cn1 : nx1;
+        n_out[3 * pc + 2] = better ? cn2 : nx2;
+    }
+}
+
+// ------------------------------------------------------------------ plane sweep --
+// _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
+// count neighbours with NCC > thresh and z > 0.1; keep the first plane with the highest
+// count.  A wave keeps the running best of its strip in LDS ((count<<16)|(65535-plane),
+// so a plain max implements torch.max's first-index rule) and never materialises the
+// (D,H,W) volume the reference allocates (:262).
+template <int K, int S>
+__global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs a)
+{
+    constexpr int HALF = K / 2;
+    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
+    constexpr float INV_AREA = 1.0f / (float)(K * K);
+    __shared__ uint32_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
+
+    const int lane = threadIdx.x;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_per_job = a.tiles_x * a.tiles_y;
+    const int job_id = t / tiles_per_job;
+    const int rem = t - job_id * tiles_per_job;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+
+    const Job &job = a.jobs[job_id];
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+    const float *__restrict__ ref = a.images + job.ref_img * a.img_stride;
+    const float *__restrict__ mean1 = a.mean1 + job.ref_img * a.img_stride;
+    const float *__restrict__ var1 = a.var1 + job.ref_img * a.img_stride;
+
+    const int xbase = tx * OUTW - HALF;
+    const int y0 = ty * a.TH;
+    const int xr = xbase + lane;
+    const bool col_in = (unsigned)xr < (unsigned)W;
+    const int trows = min(a.TH, H - y0);
+    const int rows = trows + 2 * HALF;
+
+    for (int i = 0; i < trows; ++i) best[i][lane] = 0u;
+
+    for (int d = 0; d < a.D; ++d) {
+        const float depth = a.depths[d];
+        float ring_r[K];
+        float ring_v[S][K];
+        unsigned hist_ok[HALF + 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            ring_r[i] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) ring_v[s][i] = 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i <= HALF; ++i) hist_ok[i] = 0u;
+
+        for (int r = 0; r < rows; ++r) {
+            const int yr = y0 - HALF + r;
+            const bool live = col_in && (unsigned)yr < (unsigned)H;
+            const int pix = yr * W + xr;
+            const float rv = live ? ref[pix] : 0.0f;
+            const Vec3 Pw = backproject(a.Kinv, job.Rref, job.tref, xr, yr, depth);
+            unsigned okbits = 0u;
+            float v[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                bool ok;
+                v[s] = project_sample(a.K, job.Rs[s], job.ts[s],
+                                      a.images + job.src_img[s] * a.img_stride, H, W,
+                                      -__builtin_inff(), __builtin_inff(), __builtin_inff(),
+                                      Pw, live, ok);
+                okbits |= ok ? (1u << s) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i) {
+                ring_r[i] = ring_r[i + 1];
+#pragma unroll
+                for (int s = 0; s < S; ++s) ring_v[s][i] = ring_v[s][i + 1];
+            }
+            ring_r[K - 1] = rv;
+#pragma unroll
+            for (int s = 0; s < S; ++s) ring_v[s][K - 1] = v[s];
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) hist_ok[i] = hist_ok[i + 1];
+            hist_ok[HALF] = okbits;
+            if (r < 2 * HALF) continue;
+
+            const int yc = yr - HALF;
+            const int xc = xr + HALF;
+            const bool outl = lane < OUTW && xc < W;
+            const int pc = yc * W + xc;
+            const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
+            float m1 = 0.0f, v1 = 0.0f;
+            if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
+            uint32_t votes = 0u;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float cv = ring_v[s][0];
+                float cvv = ring_v[s][0] * ring_v[s][0];
+                float crv = ring_r[0] * ring_v[s][0];
+#pragma unroll
+                for (int i = 1; i < K; ++i) {
+                    cv = cv + ring_v[s][i];
+                    cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
+                    crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
+                }
+                float bv = cv, bvv = cvv, brv = crv;
+#pragma unroll
+                for (int j = 1; j < K; ++j) {
+                    bv = wave_shl1(bv) + cv;
+                    bvv = wave_shl1(bvv) + cvv;
+                    brv = wave_shl1(brv) + crv;
+                }
+                // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
+                const float mean2 = bv * INV_AREA;
+                const float var2 = bvv * INV_AREA - mean2 * mean2;
+                const float cov = brv * INV_AREA - m1 * mean2;
+                const float ncc = cov / __builtin_sqrtf(v1 * var2 + 1e-8f);
+                if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+            }
+            if (outl) {
+                const uint32_t keyv = (votes << 16) | (uint32_t)(65535 - d);
+                const uint32_t cur = best[yc - y0][lane];
+                // plane 0 always enters (torch.max over a volume that starts at 0 votes)
+                if (d == 0 || keyv > cur) best[yc - y0][lane] = keyv;
+            }
+        }
+    }
+
+    float *__restrict__ depth_out = a.depth_out + job.slot * HW;
+    float *__restrict__ conf_out = a.conf_out + job.slot * HW;
+    const int xc = xr + HALF;
+    if (lane < OUTW && xc < W) {
+        for (int i = 0; i < trows; ++i) {
+            const uint32_t b = best[i][lane];
+            const int pc = (y0 + i) * W + xc;
+            depth_out[pc] = a.depths[65535 - (int)(b & 0xFFFFu)];      // :310
+            conf_out[pc] = (float)(b >> 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ref stats ----
+// mean / variance of a gray image under the k x k zero-padded box filter
+// (mvs_patchmatch.py:403,406): computed once per image and patch size instead of once
+// per cost evaluation.
+template <int K>
+__global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__restrict__ images,
+                                                              long long img_stride, int H, int W,
+                                                              int TH, int tiles_x, int tiles_y,
+                                                              int first_img,
+                                                              float *__restrict__ mean_out,
+                                                              float *__restrict__ var_out)
+{
+    constexpr int HALF = K / 2;
+    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
+    constexpr float INV_AREA = 1.0f / (float)(K * K);
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int img_id = first_img + t / tiles;
+    const int rem = t % tiles;
+    const int ty = rem / tiles_x, tx = rem % tiles_x;
+    const float *__restrict__ img = images + img_id * img_stride;
+    float *__restrict__ mo = mean_out + img_id * img_stride;
+    float *__restrict__ vo = var_out + img_id * img_stride;
+    const int xr = tx * OUTW - HALF + lane;
+    const int y0 = ty * TH;
+    const bool col_in = (unsigned)xr < (unsigned)W;
+    const int rows = min(TH, H - y0) + 2 * HALF;
+    float ring[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) ring[i] = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        const int yr = y0 - HALF + r;
+        const bool live = col_in && (unsigned)yr < (unsigned)H;
+        const float rv = live ? img[yr * W + xr] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring[i] = ring[i + 1];
+        ring[K - 1] = rv;
+        if (r < 2 * HALF) continue;
+        float cr = ring[0], crr = ring[0] * ring[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) { cr = cr + ring[i]; crr = __builtin_fmaf(ring[i], ring[i], crr); }
+        float br = cr, brr = crr;
+#pragma unroll
+        for (int j = 1; j < K; ++j) { br = wave_shl1(br) + cr; brr = wave_shl1(brr) + crr; }
+        const int xc = xr + HALF, yc = yr - HALF;
+        if (lane < OUTW && xc < W) {
+            const float m = br * INV_AREA;
+            mo[yc * W + xc] = m;
+            vo[yc * W + xc] = brr * INV_AREA - m * m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ init ---------
+// depth = exp(rand*(ln dmax - ln dmin) + ln dmin); normal = normalize(randn*0.3,
+// randn*0.3, -1); best_cost = +inf   (mvs_patchmatch.py:268-284)
+__global__ __launch_bounds__(256) void pm_init_kernel(const Job *__restrict__ jobs, long long HW,
+                                                      unsigned long long seed, float log_scale,
+                                                      float log_min, float *__restrict__ depth,
+                                                      float *__restrict__ normal,
+                                                      float *__restrict__ cost)
+{
+    const Job &job = jobs[blockIdx.y];
+    const StreamKey key = stream_key(seed, job.stream_view, 0u);
+    const long long base = job.slot * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW;
+         i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t h0 = pixel_hash((uint32_t)i, key);
+        depth[base + i] = exp_poly(rng_uniform(h0) * log_scale + log_min);
+        float g0, g1, g2;
+        rng_normals3(h0, g0, g1, g2);
+        float nx = g0 * 0.3f, ny = g1 * 0.3f, nz = -1.0f;
+        normalize3(nx, ny, nz);
+        normal[3 * (base + i)] = nx;
+        normal[3 * (base + i) + 1] = ny;
+        normal[3 * (base + i) + 2] = nz;
+        cost[base + i] = __builtin_inff();
+    }
+}
+
+__global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, unsigned view,
+                                                       unsigned draw, long long n,
+                                                       float *__restrict__ u_out,
+                                                       float *__restrict__ n_out)
+{
+    const StreamKey key = stream_key(seed, view, draw);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t h0 = pixel_hash((uint32_t)i, key);
+        if (u_out) u_out[i] = rng_uniform(h0);
+        if (n_out) {
+            float g0, g1, g2;
+            rng_normals3(h0, g0, g1, g2);
+            n_out[3 * i] = g0; n_out[3 * i + 1] = g1; n_out[3 * i + 2] = g2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dispatch -----
+template <int K, int S>
+static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL((pm_step_kernel<K, S>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    return hipGetLastError();
+}
+template <int K, int S>
+static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL((plane_sweep_kernel<K, S>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    return hipGetLastError();
+}
+
+#define AMVS_FOR_S(K, FN, ...)                                      \
+    switch (S) {                                                    \
+    case 2: return FN<K, 2>(__VA_ARGS__);                           \
+    case 3: return FN<K, 3>(__VA_ARGS__);                           \
+    case 4: return FN<K, 4>(__VA_ARGS__);                           \
+    case 5: return FN<K, 5>(__VA_ARGS__);                           \
+    case 6: return FN<K, 6>(__VA_ARGS__);                           \
+    default: return hipErrorInvalidValue;                           \
+    }
+
+bool patch_supported(int K) { return K == 5 || K == 7 || K == 11; }
+int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
+
+hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
+{
+    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
+    switch (K) {
+    case 5: AMVS_FOR_S(5, launch_step_ks, a, nblk, st)
+    case 7: AMVS_FOR_S(7, launch_step_ks, a, nblk, st)
+    case 11: AMVS_FOR_S(11, launch_step_ks, a, nblk, st)
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
+{
+    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
+    switch (K) {
+    case 5: AMVS_FOR_S(5, launch_sweep_ks, a, nblk, st)
+    case 7: AMVS_FOR_S(7, launch_sweep_ks, a, nblk, st)
+    case 11: AMVS_FOR_S(11, launch_sweep_ks, a, nblk, st)
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
+                            int first_img, int n_img, float *mean_out, float *var_out,
+                            hipStream_t st)
+{
+    const int TH = 32;
+    const int tiles_x = (W + strip_out_width(K) - 1) / strip_out_width(K);
+    const int tiles_y = (H + TH - 1) / TH;
+    const dim3 grid(n_img * tiles_x * tiles_y), blk(AMVS_WAVE);
+    switch (K) {
+    case 5:
+        hipLaunchKernelGGL((box_stats_kernel<5>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 7:
+        hipLaunchKernelGGL((box_stats_kernel<7>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 11:
+        hipLaunchKernelGGL((box_stats_kernel<11>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,
+                       float log_scale, float log_min, float *depth, float *normal, float *cost,
+                       hipStream_t st)
+{
+    const int bx = (int)((HW + 255) / 256 < 2048 ? (HW + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pm_init_kernel, dim3(bx, n_jobs), dim3(256), 0, st, jobs, HW, seed,
+                       log_scale, log_min, depth, normal, cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw, long long n,
+                           float *u_out, float *n_out, hipStream_t st)
+{
+    const int bx = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(bx > 0 ? bx : 1), dim3(256), 0, st, seed, view, draw, n,
+                       u_out, n_out);
+    return hipGetLastError();
+}
+
+}  // namespace amvs

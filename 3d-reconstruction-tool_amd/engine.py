@@ -1,0 +1,197 @@
+"""Engine: one device context holding every view of a scene (thin wrapper of the C ABI)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AmvsError, PmParams, Timing, f32p, i32p
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(f32p)
+
+
+def _ids(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(i32p)
+
+
+def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0):
+    """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does."""
+    log_min = np.log(float(depth_min))
+    log_max = np.log(float(depth_max))
+    return PmParams(int(patch_size), int(num_iterations), int(num_samples), int(tile_rows),
+                    float(depth_min), float(depth_max),
+                    float(np.float32(log_max - log_min)), float(np.float32(log_min)))
+
+
+class Engine:
+    def __init__(self, H, W, n_views, K, K_inv=None, device=0):
+        self._lib = _lib.load()
+        self.H, self.W, self.n_views, self.device = int(H), int(W), int(n_views), int(device)
+        self.K = _f32(np.asarray(K, np.float32).reshape(3, 3))
+        if K_inv is None:
+            # float32 inverse, as torch.inverse(K) in mvs_patchmatch.py:237-238
+            K_inv = np.linalg.inv(self.K)
+        self.K_inv = _f32(np.asarray(K_inv, np.float32).reshape(3, 3))
+        h = C.c_void_p()
+        rc = self._lib.amvs_create(self.device, self.H, self.W, self.n_views, _p(self.K), _p(self.K_inv),
+                                   C.byref(h))
+        if rc != 0:
+            raise AmvsError(f"amvs_create failed ({rc}): {self._lib.amvs_last_error(None).decode()}")
+        self._h = h
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.amvs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AmvsError(f"amvs call failed ({rc}): {self._lib.amvs_last_error(self._h).decode()}")
+
+    def sync(self):
+        self._chk(self._lib.amvs_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.amvs_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    # -- scene -------------------------------------------------------------
+    def set_view(self, view, gray, R, t):
+        gray = _f32(gray, (self.H, self.W))
+        R = _f32(np.asarray(R, np.float64).astype(np.float32).reshape(3, 3))
+        t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))
+        self._chk(self._lib.amvs_set_view(self._h, int(view), _p(gray), _p(R), _p(t)))
+
+    def set_view_device(self, view, gray_ptr, R, t):
+        R = _f32(np.asarray(R, np.float64).astype(np.float32).reshape(3, 3))
+        t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))
+        self._chk(self._lib.amvs_set_view_device(self._h, int(view), C.c_void_p(gray_ptr), _p(R), _p(t)))
+
+    # -- PatchMatch --------------------------------------------------------
+    def patchmatch(self, ref_ids, src_ids, params, seed):
+        """Returns depth (n,H,W), normal (n,H,W,3), confidence (n,H,W) as numpy arrays."""
+        ref, refp = _ids(ref_ids)
+        src, srcp = _ids(src_ids)
+        n = ref.shape[0]
+        src = src.reshape(n, -1)
+        depth = np.empty((n, self.H, self.W), np.float32)
+        normal = np.empty((n, self.H, self.W, 3), np.float32)
+        conf = np.empty((n, self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_patchmatch(self._h, n, refp, srcp, src.shape[1], C.byref(params),
+                                            int(seed), _p(depth), _p(normal), _p(conf)))
+        return depth, normal, conf
+
+    def patchmatch_device(self, ref_ids, src_ids, params, seed, depth_ptr, normal_ptr, conf_ptr):
+        ref, refp = _ids(ref_ids)
+        src, srcp = _ids(src_ids)
+        n = ref.shape[0]
+        src = src.reshape(n, -1)
+        self._chk(self._lib.amvs_patchmatch_device(self._h, n, refp, srcp, src.shape[1], C.byref(params),
+                                                   int(seed), C.c_void_p(depth_ptr),
+                                                   C.c_void_p(normal_ptr), C.c_void_p(conf_ptr)))
+
+    def timing(self):
+        t = Timing()
+        self._chk(self._lib.amvs_get_timing(self._h, C.byref(t)))
+        return {"sweep_ms": t.sweep_ms, "confidence_ms": t.confidence_ms,
+                "sweep_launches": t.sweep_launches, "pixel_hypotheses": t.pixel_hypotheses}
+
+    # -- plane sweep -------------------------------------------------------
+    def plane_sweep(self, ref, nbr_ids, depths, patch_size, thresh):
+        nbr, nbrp = _ids(nbr_ids)
+        depths = _f32(np.asarray(depths, np.float64).astype(np.float32))
+        d = np.empty((self.H, self.W), np.float32)
+        conf = np.empty((self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_plane_sweep(self._h, int(ref), nbrp, nbr.size, _p(depths), depths.size,
+                                             int(patch_size), float(thresh), _p(d), _p(conf)))
+        return d, conf
+
+    def plane_sweep_device(self, ref_ids, nbr_ids, depths, patch_size, thresh, depth_ptr, conf_ptr):
+        ref, refp = _ids(ref_ids)
+        nbr, nbrp = _ids(nbr_ids)
+        n = ref.shape[0]
+        nbr = nbr.reshape(n, -1)
+        depths = _f32(np.asarray(depths, np.float64).astype(np.float32))
+        self._chk(self._lib.amvs_plane_sweep_device(self._h, n, refp, nbrp, nbr.shape[1], _p(depths),
+                                                    depths.size, int(patch_size), float(thresh),
+                                                    C.c_void_p(depth_ptr), C.c_void_p(conf_ptr)))
+
+    # -- single steps (parity tests) ----------------------------------------
+    def eval_cost(self, ref, src_ids, patch_size, depth):
+        src, srcp = _ids(src_ids)
+        depth = _f32(depth, (self.H, self.W))
+        out = np.empty((self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_eval_cost(self._h, int(ref), srcp, src.size, int(patch_size), _p(depth), _p(out)))
+        return out
+
+    def confidence(self, ref, src_ids, patch_size, depth):
+        src, srcp = _ids(src_ids)
+        depth = _f32(depth, (self.H, self.W))
+        out = np.empty((self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_confidence(self._h, int(ref), srcp, src.size, int(patch_size), _p(depth), _p(out)))
+        return out
+
+    def _state(self, depth, normal, cost):
+        d = np.array(depth, np.float32, order="C", copy=True).reshape(self.H, self.W)
+        n = np.array(normal, np.float32, order="C", copy=True).reshape(self.H, self.W, 3)
+        c = np.array(cost, np.float32, order="C", copy=True).reshape(self.H, self.W)
+        return d, n, c
+
+    def propagate_step(self, ref, src_ids, patch_size, depth, normal, cost, oy, ox, depth_min):
+        src, srcp = _ids(src_ids)
+        d, n, c = self._state(depth, normal, cost)
+        self._chk(self._lib.amvs_propagate_step(self._h, int(ref), srcp, src.size, int(patch_size),
+                                                _p(d), _p(n), _p(c), int(oy), int(ox), float(depth_min)))
+        return d, n, c
+
+    def refine_step(self, ref, src_ids, patch_size, depth, normal, cost, seed, stream_view, draw,
+                    depth_range, normal_range, depth_min, depth_max):
+        src, srcp = _ids(src_ids)
+        d, n, c = self._state(depth, normal, cost)
+        self._chk(self._lib.amvs_refine_step(self._h, int(ref), srcp, src.size, int(patch_size),
+                                             _p(d), _p(n), _p(c), int(seed), int(stream_view), int(draw),
+                                             float(depth_range), float(normal_range),
+                                             float(depth_min), float(depth_max)))
+        return d, n, c
+
+    def init_state(self, seed, stream_view, depth_min, depth_max):
+        p = make_pm_params(7, 0, 0, depth_min, depth_max)
+        d = np.empty((self.H, self.W), np.float32)
+        n = np.empty((self.H, self.W, 3), np.float32)
+        c = np.empty((self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_init_state(self._h, int(seed), int(stream_view), p.log_depth_scale,
+                                            p.log_depth_min, _p(d), _p(n), _p(c)))
+        return d, n, c
+
+    def box_stats(self, view, patch_size):
+        m = np.empty((self.H, self.W), np.float32)
+        v = np.empty((self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_box_stats(self._h, int(view), int(patch_size), _p(m), _p(v)))
+        return m, v
+
+    def rng_fill(self, seed, stream_view, draw, n):
+        u = np.empty(n, np.float32)
+        nz = np.empty((n, 3), np.float32)
+        self._chk(self._lib.amvs_rng_fill(self._h, int(seed), int(stream_view), int(draw), int(n), _p(u), _p(nz)))
+        return u, nz

@@ -1,0 +1,138 @@
+/*
+ * amvs.h -- C ABI of the MI355X-native dense-reconstruction backend.
+ *
+ * The reference (dackey-wav/3d-reconstruction-tool) has no FFI: its dense path is a
+ * Python class surface that runs stock torch ops.  These entry points are what a
+ * ctypes binding of that surface needs; each cites the reference interface it
+ * replaces (file:line under the reference's src/core/).  Plain pointers and
+ * sizes only, no C++ or torch types.  Every call returns 0 on success or a
+ * negative AMVS_E* code; amvs_last_error() returns a description.
+ *
+ * Conventions:
+ *   - images are float32 gray maps in [0,1], row-major (H,W), one size per context
+ *     (mvs_patchmatch.py:183-189 'gray'); all views share one K (camera.py:111-139)
+ *   - poses are world->camera, X_c = R X_w + t, R row-major (camera.py:78-103)
+ *   - depth/cost/confidence maps are float32 (H,W); normal maps float32 (H,W,3)
+ *     interleaved xyz (mvs_patchmatch.py:30-35 DepthNormalMap)
+ *   - host buffers are caller-owned and C-contiguous; *_device variants take
+ *     device pointers (e.g. torch tensor .data_ptr()) and enqueue on the
+ *     context's stream without synchronising.
+ */
+#ifndef AMVS_H
+#define AMVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMVS_MAX_SRC 6      /* PatchMatch uses 4 (mvs_patchmatch.py:108), plane sweep 6 (dense_stereo.py:109) */
+
+#define AMVS_OK            0
+#define AMVS_EINVAL       -1   /* bad argument                                  */
+#define AMVS_EHIP         -2   /* HIP runtime error (no device, OOM, launch)    */
+#define AMVS_EUNSUPPORTED -3   /* patch size / source count not compiled in     */
+
+typedef struct amvs_ctx amvs_ctx;
+
+/* PatchMatchMVS constructor parameters that reach the device path
+ * (mvs_patchmatch.py:43-50) plus the depth range of _estimate_depth_range
+ * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
+ * and (float)ln dmin formed in double by the host, as :268-271 does.           */
+typedef struct {
+    int32_t patch_size;       /* odd; compiled: 5, 7, 11                          */
+    int32_t num_iterations;
+    int32_t num_samples;
+    int32_t tile_rows;        /* rows per wave strip; 0 = choose automatically    */
+    float   depth_min, depth_max;
+    float   log_depth_scale, log_depth_min;
+} amvs_pm_params;
+
+/* Per-call device timing of the sweep kernels (HIP events on the context
+ * stream; used by bench.py for the roofline figure).                            */
+typedef struct {
+    double  sweep_ms;         /* init + propagation + refinement launches          */
+    double  confidence_ms;    /* confidence launch                                 */
+    int64_t sweep_launches;
+    int64_t pixel_hypotheses; /* n_ref * H * W * iters * (2 + samples)            */
+} amvs_timing;
+
+const char *amvs_version(void);
+const char *amvs_last_error(const amvs_ctx *ctx);   /* ctx may be NULL: error of a failed amvs_create */
+
+/* A context owns all device memory for one scene: n_views gray images of H x W
+ * with shared intrinsics K (row-major 3x3) and K_inv (the reference forms it with
+ * torch.inverse in float32, mvs_patchmatch.py:237-238; the caller passes it).   */
+int amvs_create(int device_id, int H, int W, int n_views,
+                const float K[9], const float K_inv[9], amvs_ctx **out);
+int amvs_destroy(amvs_ctx *ctx);
+int amvs_set_stream(amvs_ctx *ctx, void *hip_stream);     /* NULL = context's own stream */
+int amvs_sync(amvs_ctx *ctx);
+
+/* Upload one view once per scene (the reference re-uploads every view for every
+ * reference view, mvs_patchmatch.py:235-257).                                     */
+int amvs_set_view(amvs_ctx *ctx, int view, const float *gray_host,
+                  const float R[9], const float t[3]);
+int amvs_set_view_device(amvs_ctx *ctx, int view, const void *gray_device,
+                         const float R[9], const float t[3]);
+
+/* PatchMatchMVS._patchmatch_cuda (mvs_patchmatch.py:225-321) for n_ref reference
+ * views in one batch.  src_ids is [n_ref][n_src].  Outputs are [n_ref][H][W]
+ * (depth, confidence) and [n_ref][H][W][3] (normal).  The RNG stream of a view is
+ * (seed, ref_ids[i]); see amvs_rng_fill.                                          */
+int amvs_patchmatch(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids,
+                    int n_src, const amvs_pm_params *p, uint64_t seed,
+                    float *depth_out, float *normal_out, float *conf_out);
+int amvs_patchmatch_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids,
+                           int n_src, const amvs_pm_params *p, uint64_t seed,
+                           void *depth_dev, void *normal_dev, void *conf_dev);
+int amvs_get_timing(const amvs_ctx *ctx, amvs_timing *out);
+
+/* DenseStereoReconstructor._plane_sweep_torch (dense_stereo.py:222-316) for one
+ * reference view: D depth planes, votes (ncc > thresh) & (z > 0.1) over n_nbr
+ * neighbours, first maximal plane wins.                                          */
+int amvs_plane_sweep(amvs_ctx *ctx, int ref, const int *nbr_ids, int n_nbr,
+                     const float *depths, int D, int patch_size, float thresh,
+                     float *depth_out, float *conf_out);
+int amvs_plane_sweep_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *nbr_ids,
+                            int n_nbr, const float *depths, int D, int patch_size,
+                            float thresh, void *depth_dev, void *conf_dev);
+
+/* ---- single-step entry points (parity tests drive these one reference call at a time) ---- */
+
+/* _compute_patch_cost (mvs_patchmatch.py:323-390): depth map in, averaged cost out. */
+int amvs_eval_cost(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
+                   const float *depth_in, float *cost_out);
+/* _compute_confidence (mvs_patchmatch.py:493-534). */
+int amvs_confidence(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
+                    const float *depth_in, float *conf_out);
+/* One pull step of _spatial_propagation (mvs_patchmatch.py:427-455): candidate at
+ * (y,x) is the state at (y+oy, x+ox); state arrays are updated in place.          */
+int amvs_propagate_step(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
+                        float *depth, float *normal, float *cost,
+                        int oy, int ox, float depth_min);
+/* One sample of _random_refinement (mvs_patchmatch.py:470-489) with draw `draw`
+ * of stream (seed, stream_view).                                                  */
+int amvs_refine_step(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
+                     float *depth, float *normal, float *cost,
+                     uint64_t seed, uint32_t stream_view, uint32_t draw,
+                     float depth_range, float normal_range,
+                     float depth_min, float depth_max);
+/* Initialisation (mvs_patchmatch.py:268-284) from draw 0 of stream (seed, stream_view). */
+int amvs_init_state(amvs_ctx *ctx, uint64_t seed, uint32_t stream_view,
+                    float log_depth_scale, float log_depth_min,
+                    float *depth, float *normal, float *cost);
+/* mean / variance maps of view `view` under a k x k zero-padded box filter
+ * (mvs_patchmatch.py:403,406).                                                    */
+int amvs_box_stats(amvs_ctx *ctx, int view, int patch_size, float *mean_out, float *var_out);
+/* The counter-hash RNG that stands in for torch.rand / torch.randn
+ * (mvs_patchmatch.py:271,279,280,471,475): per element one uniform (u_out, n
+ * floats) and three normals (n_out, n x 3).  Either output may be NULL.           */
+int amvs_rng_fill(amvs_ctx *ctx, uint64_t seed, uint32_t stream_view, uint32_t draw,
+                  int64_t n, float *u_out, float *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMVS_H */

@@ -1,0 +1,89 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+class GoldenScene:
+    """A committed synthetic scene (tests/golden/scene_*.npz): u8 images, poses, intrinsics."""
+
+    def __init__(self, name):
+        g = load_golden(name)
+        self.gray_u8 = g["gray_u8"]
+        self.grays = [(x.astype(np.float32) / np.float32(255.0)) for x in self.gray_u8]
+        self.colors = list(g["color_u8"])
+        self.K = g["K"]
+        self.R = g["R"]
+        self.t = g["t"]
+        self.depth_min = float(g["depth_min"])
+        self.depth_max = float(g["depth_max"])
+        self.gt_depth = g["gt_depth"]
+        self.n = len(self.grays)
+        self.H, self.W = self.grays[0].shape
+
+    def poses(self):
+        import amvs
+        return {i: amvs.CameraPose(R=self.R[i].copy(), t=self.t[i].copy()) for i in range(self.n)}
+
+    def K32(self):
+        return self.K.astype(np.float32)
+
+    def oracle_ctx(self, ref, srcs, patch):
+        from oracle import oracle
+        return oracle.ViewContext(self.K32(), self.grays[ref], self.R[ref], self.t[ref],
+                                  [self.grays[i] for i in srcs], [self.R[i] for i in srcs],
+                                  [self.t[i] for i in srcs], patch)
+
+    def engine(self):
+        import amvs
+        eng = amvs.Engine(self.H, self.W, self.n, self.K32())
+        for i in range(self.n):
+            eng.set_view(i, self.grays[i], self.R[i], self.t[i])
+        return eng
+
+
+@pytest.fixture(scope="session")
+def scene_a():
+    return GoldenScene("scene_a")
+
+
+@pytest.fixture(scope="session")
+def scene_b():
+    return GoldenScene("scene_b")
+
+
+@pytest.fixture(scope="session")
+def scene_c():
+    return GoldenScene("scene_c")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    from oracle import oracle
+    oracle.build()
+
+
+def assert_cost_close(got, want, atol, what=""):
+    """Cost maps: identical +inf / NaN pattern, finite values within atol."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape
+    assert np.array_equal(np.isposinf(got), np.isposinf(want)), f"{what}: +inf pattern differs"
+    fin = np.isfinite(want) & np.isfinite(got)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern differs"
+    err = np.abs(got[fin] - want[fin])
+    assert err.size == 0 or err.max() <= atol, f"{what}: max abs err {err.max():.3e} > {atol:.1e}"
