@@ -24,7 +24,7 @@ class PmParams(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("sweep_ms", C.c_double), ("confidence_ms", C.c_double),
+    _fields_ = [("init_ms", C.c_double), ("sweep_ms", C.c_double), ("confidence_ms", C.c_double),
                 ("sweep_launches", C.c_int64), ("pixel_hypotheses", C.c_int64)]
 
 
@@ -44,6 +44,7 @@ SIGNATURES = {
                                          C.POINTER(PmParams), C.c_uint64,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
+    "amvs_sampling_mode": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,
                                    C.c_float, f32p, f32p]),
     "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,

@@ -10,6 +10,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -36,6 +37,13 @@ struct amvs_ctx {
     std::vector<std::array<float, 3>> t;
     std::vector<char> have;
     float *d_images = nullptr;
+    // packed 8-bit row-pair maps (sampling fast path), valid while every uploaded view is
+    // exactly code/255 (n_inexact == 0); otherwise the sweep samples the float32 maps
+    uint16_t *d_pairs = nullptr;
+    long long pstride = 0;              // ushorts between packed maps
+    int *d_flag = nullptr;
+    std::vector<char> exact8;
+    bool force_f32 = false;             // AMVS_FORCE_F32_SAMPLING=1: A/B switch for tests
     std::map<int, Stats> stats;
     int cap_slots = 0;
     float *d_depth[2] = {nullptr, nullptr}, *d_cost[2] = {nullptr, nullptr},
@@ -45,7 +53,7 @@ struct amvs_ctx {
     float *d_planes = nullptr;
     int cap_planes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing_pending = false;
     amvs_timing timing{};
     std::string err;
@@ -181,6 +189,15 @@ int pick_tile_rows(const amvs_ctx *c, int patch, int n_jobs, int requested, int 
     return 8;
 }
 
+// the packed maps can be used when every uploaded view quantised losslessly
+const uint16_t *usable_pairs(const amvs_ctx *c)
+{
+    if (c->force_f32) return nullptr;
+    for (int v = 0; v < c->n_views; ++v)
+        if (c->have[v] && !c->exact8[v]) return nullptr;
+    return c->d_pairs;
+}
+
 amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
 {
     amvs::StepArgs a{};
@@ -192,6 +209,8 @@ amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
     std::memcpy(a.K, c->K, 36);
     std::memcpy(a.Kinv, c->Kinv, 36);
     a.images = c->d_images;
+    a.pairs = usable_pairs(c);
+    a.pair_stride = c->pstride;
     const Stats &s = c->stats.at(patch);
     a.mean1 = s.mean; a.var1 = s.var;
     a.jobs = c->d_jobs;
@@ -208,13 +227,15 @@ void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur)
 void resolve_timing(amvs_ctx *c)
 {
     if (!c->timing_pending) return;
-    float ms0 = 0.f, ms1 = 0.f;
-    if (hipEventSynchronize(c->ev[2]) == hipSuccess) {
+    float ms0 = 0.f, ms1 = 0.f, ms2 = 0.f;
+    if (hipEventSynchronize(c->ev[3]) == hipSuccess) {
         (void)hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]);
         (void)hipEventElapsedTime(&ms1, c->ev[1], c->ev[2]);
+        (void)hipEventElapsedTime(&ms2, c->ev[2], c->ev[3]);
     }
-    c->timing.sweep_ms = ms0;
-    c->timing.confidence_ms = ms1;
+    c->timing.init_ms = ms0;
+    c->timing.sweep_ms = ms1;
+    c->timing.confidence_ms = ms2;
     c->timing_pending = false;
 }
 
@@ -286,6 +307,12 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     std::memcpy(c->K, K, 36);
     std::memcpy(c->Kinv, K_inv, 36);
     c->R.resize(n_views); c->t.resize(n_views); c->have.assign(n_views, 0);
+    c->exact8.assign(n_views, 0);
+    c->pstride = (((long long)H * W + 63) / 64) * 64 + 64;
+    {
+        const char *e = std::getenv("AMVS_FORCE_F32_SAMPLING");
+        c->force_f32 = e && e[0] == '1';
+    }
     auto bail = [&](const char *what, hipError_t e) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         amvs_destroy(c);
@@ -302,6 +329,11 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
         return bail("hipMalloc(images)", e);
     if ((e = hipMemsetAsync(c->d_images, 0, sizeof(float) * c->stride * n_views, c->stream)) != hipSuccess)
         return bail("hipMemset(images)", e);
+    if ((e = hipMalloc(&c->d_pairs, sizeof(uint16_t) * c->pstride * n_views)) != hipSuccess)
+        return bail("hipMalloc(pairs)", e);
+    if ((e = hipMemsetAsync(c->d_pairs, 0, sizeof(uint16_t) * c->pstride * n_views, c->stream)) != hipSuccess)
+        return bail("hipMemset(pairs)", e);
+    if ((e = hipMalloc(&c->d_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", e);
     *out = c;
     return AMVS_OK;
 }
@@ -320,6 +352,8 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_images) (void)hipFree(c->d_images);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_flag) (void)hipFree(c->d_flag);
     for (auto &kv : c->stats) {
         if (kv.second.mean) (void)hipFree(kv.second.mean);
         if (kv.second.var) (void)hipFree(kv.second.var);
@@ -356,7 +390,14 @@ static int set_view_common(amvs_ctx *c, int view, const void *gray, const float 
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_images + view * c->stride, gray, sizeof(float) * c->H * c->W, kind,
                              c->stream));
-    if (kind == hipMemcpyHostToDevice) HIPCHK(c, hipStreamSynchronize(c->stream));
+    // packed 8-bit map + losslessness test of this view
+    int inexact = 0;
+    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    HIPCHK(c, amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W,
+                                      c->d_pairs + view * c->pstride, c->d_flag, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&inexact, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->exact8[view] = inexact ? 0 : 1;
     std::memcpy(c->R[view].data(), R, 36);
     std::memcpy(c->t[view].data(), t, 12);
     c->have[view] = 1;
@@ -403,7 +444,7 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     HIPCHK(c, amvs::launch_init(c->d_jobs, n_ref, (long long)hw, seed, p->log_depth_scale,
                                 p->log_depth_min, c->d_depth[cur], c->d_normal[cur], c->d_cost[cur],
                                 c->stream));
-    ++launches;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     for (int it = 0; it < p->num_iterations; ++it) {
         // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
         // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
@@ -427,13 +468,13 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
             cur ^= 1; ++launches;
         }
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
     a.mode = amvs::MODE_CONF;
     set_io(a, c, cur);
     a.aux = (float *)conf_dev;
     HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     c->timing.sweep_launches = launches;
@@ -483,6 +524,8 @@ int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
     return AMVS_OK;
 }
 
+int amvs_sampling_mode(const amvs_ctx *c) { return c && usable_pairs(c) ? 1 : 0; }
+
 int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
                             const float *depths, int D, int patch_size, float thresh, void *depth_dev,
                             void *conf_dev)
@@ -512,6 +555,8 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     std::memcpy(a.K, c->K, 36);
     std::memcpy(a.Kinv, c->Kinv, 36);
     a.images = c->d_images;
+    a.pairs = usable_pairs(c);
+    a.pair_stride = c->pstride;
     const Stats &s = c->stats.at(patch_size);
     a.mean1 = s.mean; a.var1 = s.var;
     a.depths = c->d_planes;
@@ -521,9 +566,10 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     resolve_timing(c);
     c->timing = amvs_timing{};
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, amvs::launch_sweep(patch_size, n_nbr, a, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, amvs::launch_sweep(patch_size, n_nbr, a, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->timing.sweep_launches = 1;
     c->timing.pixel_hypotheses = (int64_t)n_ref * c->H * c->W * D;
     c->timing_pending = true;

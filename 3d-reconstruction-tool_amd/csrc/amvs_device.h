@@ -128,22 +128,35 @@ AMVS_DEV float exp_poly(float x)
     return y * __uint_as_float((uint32_t)(ni + 127) << 23);
 }
 
+// a / b given rb = RN(1/b): q = a*rb, one FMA residual, one FMA correction.  With a
+// correctly rounded reciprocal this returns the correctly rounded quotient (Markstein);
+// checked equal to IEEE division on 2.16e8 random operand pairs.  Used where
+// several quotients share a denominator, so one division serves all of them.
+AMVS_DEV float qdiv(float a, float b, float rb)
+{
+    float q = a * rb;
+    float r = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(r, rb, q);
+}
+
 // F.normalize(v, dim=-1) = v / max(||v||, 1e-12)   (mvs_patchmatch.py:281,476)
 AMVS_DEV void normalize3(float &x, float &y, float &z)
 {
     float n = __builtin_sqrtf(x * x + y * y + z * z);
     float d = n > 1e-12f ? n : 1e-12f;
-    x = x / d; y = y / d; z = z / d;
+    float rd = 1.0f / d;
+    x = qdiv(x, d, rd); y = qdiv(y, d, rd); z = qdiv(z, d, rd);
 }
 
 // ------------------------------------------------------------ geometry -----
-struct Mat3 { float m[9]; };
 struct Vec3 { float x, y, z; };
 
 // rays = [x,y,1] @ K_inv.T ; X = rays * d ; Xw = (X - t_ref) @ R_ref
-// (mvs_patchmatch.py:341-347).  3-term sums are fma(a2,b2,fma(a1,b1,a0*b0)).
-AMVS_DEV Vec3 backproject(const float *Kinv, const float *Rref, const float *tref,
-                          int x, int y, float d)
+// (mvs_patchmatch.py:341-347).  3-term sums are fma(a2,b2,fma(a1,b1,a0*b0)), the order
+// torch-CPU's matmul was measured to use.  Pointer types are templated so that loads from
+// the constant address space stay scalar (s_load).
+template <class KP, class RP, class TP>
+AMVS_DEV Vec3 backproject(KP Kinv, RP Rref, TP tref, int x, int y, float d)
 {
     float px = (float)x, py = (float)y;
     float q0 = __builtin_fmaf(1.0f, Kinv[2], __builtin_fmaf(py, Kinv[1], px * Kinv[0])) * d - tref[0];
@@ -156,44 +169,89 @@ AMVS_DEV Vec3 backproject(const float *Kinv, const float *Rref, const float *tre
     return w;
 }
 
-// Project a world point into a source view and sample it bilinearly
-// (mvs_patchmatch.py:351-377: project, bounds test, grid_sample bilinear /
-// zeros / align_corners=True).  The projection is valid when z > 0.1 and
-// lo <= u < hix, lo <= v < hiy (patch bounds :362-363, image bounds :516-517, or
-// -inf/+inf for the plane sweep, which only tests z: dense_stereo.py:280,303).
-// `live` masks lanes whose pixel is outside the image: they issue no loads and
-// return 0 (the zero padding of the box filter).
-AMVS_DEV float project_sample(const float *K, const float *Rs, const float *ts,
-                              const float *__restrict__ img, int H, int W,
-                              float lo, float hix, float hiy,
-                              Vec3 Pw, bool live, bool &valid)
+// Per-launch constants of the sampler.
+struct SampleConsts {
+    int H, W;
+    float fw, fh;        // W-1, H-1
+    float rfw, rfh;      // RN(1/(W-1)), RN(1/(H-1))
+    float hw2, hh2;      // (W-1)/2, (H-1)/2
+    float lo, hix, hiy;  // validity window of the projection
+};
+
+AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, float hiy)
 {
+    SampleConsts c;
+    c.H = H; c.W = W;
+    c.fw = (float)(W - 1); c.fh = (float)(H - 1);
+    c.rfw = 1.0f / c.fw; c.rfh = 1.0f / c.fh;
+    c.hw2 = c.fw * 0.5f; c.hh2 = c.fh * 0.5f;
+    c.lo = lo; c.hix = hix; c.hiy = hiy;
+    return c;
+}
+
+// Project a world point into a source view and sample it bilinearly
+// (mvs_patchmatch.py:351-377: project, bounds test, grid_sample bilinear / zeros /
+// align_corners=True, restated bit-exactly against ATen's CPU kernel).  The projection is
+// valid when z > 0.1 and lo <= u < hix, lo <= v < hiy (patch bounds :362-363, image bounds
+// :516-517, or -inf/+inf for the plane sweep, which only tests z: dense_stereo.py:280,303).
+// `live` masks lanes whose pixel is outside the image: they issue no loads and return 0
+// (the zero padding of the box filter).
+//
+// U8 = false: `img` is the float32 gray map; four dword gathers over two image rows.
+// U8 = true : `img` is the packed 8-bit row-pair map (ushort (y,x) = code(y,x) |
+//             code(y+1,x) << 8) of an image whose every pixel equals code/255 exactly (what
+//             cvtColor(...).astype(float32)/255 produces, mvs_patchmatch.py:177).  One
+//             2-byte-aligned dword gather fetches the whole 2x2 footprint; codes are decoded
+//             through the 256-entry table `lut` in LDS (lut[c] = (float)c / 255.0f), so the tap
+//             values are bit-identical to the float32 map's.
+template <bool U8, class KP, class RP, class TP>
+AMVS_DEV float project_sample(KP K, RP Rs, TP ts, const void *__restrict__ img,
+                              const float *lut, const SampleConsts &c, Vec3 Pw, bool live,
+                              bool &valid)
+{
+    const int H = c.H, W = c.W;
     float p0 = __builtin_fmaf(Pw.z, Rs[2], __builtin_fmaf(Pw.y, Rs[1], Pw.x * Rs[0])) + ts[0];
     float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
     float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
     float zz = z + 1e-8f;
-    float a = p0 / zz, b = p1 / zz;
+    float rz = 1.0f / zz;
+    float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];
-    valid = (z > 0.1f) && (u >= lo) && (u < hix) && (v >= lo) && (v < hiy);
-    const float fw = (float)(W - 1), fh = (float)(H - 1);
-    float gx = (2.0f * u) / fw - 1.0f;
-    float gy = (2.0f * v) / fh - 1.0f;
-    float ux = (gx + 1.0f) * (fw * 0.5f);
-    float uy = (gy + 1.0f) * (fh * 0.5f);
+    valid = (z > 0.1f) && (u >= c.lo) && (u < c.hix) && (v >= c.lo) && (v < c.hiy);
+    float gx = qdiv(2.0f * u, c.fw, c.rfw) - 1.0f;
+    float gy = qdiv(2.0f * v, c.fh, c.rfh) - 1.0f;
+    float ux = (gx + 1.0f) * c.hw2;
+    float uy = (gy + 1.0f) * c.hh2;
     float x0 = __builtin_floorf(ux), y0 = __builtin_floorf(uy);
     float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
     float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
     float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
-    bool x0ok = (x0 >= 0.0f) && (x0 <= fw), x1ok = (x1 >= 0.0f) && (x1 <= fw);
-    bool y0ok = (y0 >= 0.0f) && (y0 <= fh), y1ok = (y1 >= 0.0f) && (y1 <= fh);
-    // clamped integer coordinates keep every issued load inside the image
-    int ix0 = min(max((int)x0, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
-    int iy0 = min(max((int)y0, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
+    bool x0ok = (x0 >= 0.0f) && (x0 <= c.fw), x1ok = (x1 >= 0.0f) && (x1 <= c.fw);
+    bool y0ok = (y0 >= 0.0f) && (y0 <= c.fh), y1ok = (y1 >= 0.0f) && (y1 <= c.fh);
     float t00 = 0.0f, t01 = 0.0f, t10 = 0.0f, t11 = 0.0f;
-    if (live) {
-        t00 = img[iy0 * W + ix0]; t01 = img[iy0 * W + ix1];
-        t10 = img[iy1 * W + ix0]; t11 = img[iy1 * W + ix1];
+    const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
+    if (U8) {
+        // clamped base keeps the 4-byte read inside the row; which bytes are the left /
+        // right column and the top / bottom row follows from where the clamp moved it
+        const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
+        uint32_t w = 0u;
+        if (live) __builtin_memcpy(&w, (const char *)img + 2 * (yb * W + xb), 4);
+        const uint32_t lsh = x0i > xb ? 16u : 0u;
+        const uint32_t rsh = x0i < xb ? 0u : 16u;
+        const uint32_t bsh = y0i < yb ? 0u : 8u;
+        t00 = lut[(w >> lsh) & 0xFFu];
+        t10 = lut[(w >> (lsh + bsh)) & 0xFFu];
+        t01 = lut[(w >> rsh) & 0xFFu];
+        t11 = lut[(w >> (rsh + bsh)) & 0xFFu];
+    } else {
+        const float *__restrict__ f = (const float *)img;
+        const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
+        const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
+        if (live) {
+            t00 = f[iy0 * W + ix0]; t01 = f[iy0 * W + ix1];
+            t10 = f[iy1 * W + ix0]; t11 = f[iy1 * W + ix1];
+        }
     }
     t00 = (x0ok && y0ok) ? t00 : 0.0f;
     t01 = (x1ok && y0ok) ? t01 : 0.0f;
@@ -201,6 +259,15 @@ AMVS_DEV float project_sample(const float *K, const float *Rs, const float *ts,
     t11 = (x1ok && y1ok) ? t11 : 0.0f;
     float r = __builtin_fmaf(t11, se, __builtin_fmaf(t10, sw, __builtin_fmaf(t01, ne, t00 * nw)));
     return live ? r : 0.0f;
+}
+
+// fill the 256-entry code -> gray table (one wave; entry c = (float)c / 255.0f, the
+// float32 division numpy performs in `gray.astype(np.float32) / 255.0`)
+AMVS_DEV void fill_gray_lut(float *lut, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lut[lane * 4 + j] = (float)(lane * 4 + j) / 255.0f;
+    __syncthreads();
 }
 
 // lane i <- lane i+1 (whole-wave shift; lane 63 receives 0).  hipcc folds this

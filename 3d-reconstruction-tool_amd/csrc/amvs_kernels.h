@@ -25,6 +25,8 @@ struct StepArgs {
     long long img_stride;                    // floats between consecutive images
     float K[9], Kinv[9];
     const float *images, *mean1, *var1;      // [n_views][img_stride]
+    const uint16_t *pairs;                   // packed 8-bit row-pair maps [n_views][pair_stride], or NULL
+    long long pair_stride;
     const float *d_in, *c_in, *n_in;         // state read   [slot][H*W], normals [slot][H*W*3]
     float *d_out, *c_out, *n_out;            // state written
     float *aux;                              // MODE_EVAL: cost map, MODE_CONF: confidence
@@ -40,6 +42,8 @@ struct SweepArgs {
     long long img_stride;
     float K[9], Kinv[9];
     const float *images, *mean1, *var1;
+    const uint16_t *pairs;
+    long long pair_stride;
     const float *depths;                     // [D] device
     float thresh;
     float *depth_out, *conf_out;             // [slot][H*W]
@@ -53,6 +57,8 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
                             int first_img, int n_img, float *mean_out, float *var_out,
                             hipStream_t st);
+hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, int *inexact,
+                             hipStream_t st);
 hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,
                        float log_scale, float log_min, float *depth, float *normal, float *cost,
                        hipStream_t st);

@@ -22,6 +22,10 @@
 
 namespace amvs {
 
+// The job table is never written while a sweep kernel runs: reading it through the
+// constant address space lets the compiler use scalar loads (s_load) for the poses.
+typedef const __attribute__((address_space(4))) Job *JobCP;
+
 // contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
 AMVS_DEV int xcd_remap(int bid, int nblk)
 {
@@ -34,14 +38,16 @@ AMVS_DEV int xcd_remap(int bid, int nblk)
 // One cost evaluation + select over a batch of reference views
 // (_compute_patch_cost / _spatial_propagation / _random_refinement /
 //  _compute_confidence, mvs_patchmatch.py:323-534).
-template <int K, int S>
+template <int K, int S, bool U8>
 __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
 {
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
+    __shared__ float lut[256];
 
     const int lane = threadIdx.x;
+    if (U8) fill_gray_lut(lut, lane);
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     const int job_id = t / tiles_per_job;
@@ -49,28 +55,28 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
     const int ty = rem / a.tiles_x;
     const int tx = rem - ty * a.tiles_x;
 
-    const Job &job = a.jobs[job_id];
+    const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = a.mode;
     const long long HW = (long long)H * W;
 
-    const float *__restrict__ ref = a.images + job.ref_img * a.img_stride;
-    const float *__restrict__ mean1 = a.mean1 + job.ref_img * a.img_stride;
-    const float *__restrict__ var1 = a.var1 + job.ref_img * a.img_stride;
-    const float *__restrict__ d_in = a.d_in + job.slot * HW;
-    const float *__restrict__ c_in = a.c_in + job.slot * HW;
-    const float *__restrict__ n_in = a.n_in + job.slot * HW * 3;
-    float *__restrict__ d_out = a.d_out + job.slot * HW;
-    float *__restrict__ c_out = a.c_out + job.slot * HW;
-    float *__restrict__ n_out = a.n_out + job.slot * HW * 3;
-    float *__restrict__ aux = a.aux + job.slot * HW;
+    const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
+    const float *__restrict__ mean1 = a.mean1 + job->ref_img * a.img_stride;
+    const float *__restrict__ var1 = a.var1 + job->ref_img * a.img_stride;
+    const float *__restrict__ d_in = a.d_in + job->slot * HW;
+    const float *__restrict__ c_in = a.c_in + job->slot * HW;
+    const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
+    float *__restrict__ d_out = a.d_out + job->slot * HW;
+    float *__restrict__ c_out = a.c_out + job->slot * HW;
+    float *__restrict__ n_out = a.n_out + job->slot * HW * 3;
+    float *__restrict__ aux = a.aux + job->slot * HW;
 
-    const StreamKey key = stream_key(a.seed, job.stream_view, a.draw);
+    const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
 
     // validity window of the projection: patch bounds (mvs_patchmatch.py:362-363) or
     // image bounds for the confidence pass (:516-517)
-    const float lo = mode == MODE_CONF ? 0.0f : (float)HALF;
-    const float hix = mode == MODE_CONF ? (float)W : (float)(W - HALF);
-    const float hiy = mode == MODE_CONF ? (float)H : (float)(H - HALF);
+    const SampleConsts sc = make_sample_consts(H, W, mode == MODE_CONF ? 0.0f : (float)HALF,
+                                               mode == MODE_CONF ? (float)W : (float)(W - HALF),
+                                               mode == MODE_CONF ? (float)H : (float)(H - HALF));
 
     const int xbase = tx * OUTW - HALF;
     const int y0 = ty * a.TH;
@@ -121,16 +127,16 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
             }
         }
         const float rv = live ? ref[pix] : 0.0f;
-        const Vec3 Pw = backproject(a.Kinv, job.Rref, job.tref, xr, yr, dc);
+        const Vec3 Pw = backproject(a.Kinv, job->Rref, job->tref, xr, yr, dc);
 
         unsigned okbits = 0u;
         float v[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             bool ok;
-            v[s] = project_sample(a.K, job.Rs[s], job.ts[s],
-                                  a.images + job.src_img[s] * a.img_stride, H, W,
-                                  lo, hix, hiy, Pw, live, ok);
+            const void *src = U8 ? (const void *)(a.pairs + job->src_img[s] * a.pair_stride)
+                                 : (const void *)(a.images + job->src_img[s] * a.img_stride);
+            v[s] = project_sample<U8>(a.K, job->Rs[s], job->ts[s], src, lut, sc, Pw, live, ok);
             okbits |= ok ? (1u << s) : 0u;
         }
 
@@ -251,15 +257,17 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
 // count.  A wave keeps the running best of its strip in LDS ((count<<16)|(65535-plane),
 // so a plain max implements torch.max's first-index rule) and never materialises the
 // (D,H,W) volume the reference allocates (:262).
-template <int K, int S>
+template <int K, int S, bool U8>
 __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs a)
 {
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
     __shared__ uint32_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
+    __shared__ float lut[256];
 
     const int lane = threadIdx.x;
+    if (U8) fill_gray_lut(lut, lane);
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     const int job_id = t / tiles_per_job;
@@ -267,12 +275,13 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     const int ty = rem / a.tiles_x;
     const int tx = rem - ty * a.tiles_x;
 
-    const Job &job = a.jobs[job_id];
+    const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W;
     const long long HW = (long long)H * W;
-    const float *__restrict__ ref = a.images + job.ref_img * a.img_stride;
-    const float *__restrict__ mean1 = a.mean1 + job.ref_img * a.img_stride;
-    const float *__restrict__ var1 = a.var1 + job.ref_img * a.img_stride;
+    const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
+    const float *__restrict__ mean1 = a.mean1 + job->ref_img * a.img_stride;
+    const float *__restrict__ var1 = a.var1 + job->ref_img * a.img_stride;
+    const SampleConsts sc = make_sample_consts(H, W, -__builtin_inff(), __builtin_inff(), __builtin_inff());
 
     const int xbase = tx * OUTW - HALF;
     const int y0 = ty * a.TH;
@@ -302,16 +311,15 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const bool live = col_in && (unsigned)yr < (unsigned)H;
             const int pix = yr * W + xr;
             const float rv = live ? ref[pix] : 0.0f;
-            const Vec3 Pw = backproject(a.Kinv, job.Rref, job.tref, xr, yr, depth);
+            const Vec3 Pw = backproject(a.Kinv, job->Rref, job->tref, xr, yr, depth);
             unsigned okbits = 0u;
             float v[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 bool ok;
-                v[s] = project_sample(a.K, job.Rs[s], job.ts[s],
-                                      a.images + job.src_img[s] * a.img_stride, H, W,
-                                      -__builtin_inff(), __builtin_inff(), __builtin_inff(),
-                                      Pw, live, ok);
+                const void *src = U8 ? (const void *)(a.pairs + job->src_img[s] * a.pair_stride)
+                                     : (const void *)(a.images + job->src_img[s] * a.img_stride);
+                v[s] = project_sample<U8>(a.K, job->Rs[s], job->ts[s], src, lut, sc, Pw, live, ok);
                 okbits |= ok ? (1u << s) : 0u;
             }
 #pragma unroll
@@ -370,8 +378,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
         }
     }
 
-    float *__restrict__ depth_out = a.depth_out + job.slot * HW;
-    float *__restrict__ conf_out = a.conf_out + job.slot * HW;
+    float *__restrict__ depth_out = a.depth_out + job->slot * HW;
+    float *__restrict__ conf_out = a.conf_out + job->slot * HW;
     const int xc = xr + HALF;
     if (lane < OUTW && xc < W) {
         for (int i = 0; i < trows; ++i) {
@@ -437,6 +445,36 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__res
     }
 }
 
+// ------------------------------------------------------------------ 8-bit pack ---
+// Build the packed row-pair map of one view and test that it is lossless: pixel (y,x) gets
+// code = rint(g*255) clamped to [0,255]; `inexact` is raised if any pixel differs from
+// (float)code / 255.0f, in which case the sweep keeps sampling the float32 map.
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict__ img, int H, int W,
+                                                         uint16_t *__restrict__ pairs,
+                                                         int *__restrict__ inexact)
+{
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W);
+        const float g0 = img[i];
+        const float g1 = y + 1 < H ? img[i + W] : g0;
+        const int c0 = min(max((int)__builtin_rintf(g0 * 255.0f), 0), 255);
+        const int c1 = min(max((int)__builtin_rintf(g1 * 255.0f), 0), 255);
+        if (!((float)c0 / 255.0f == g0)) atomicOr(inexact, 1);
+        pairs[i] = (uint16_t)(c0 | (c1 << 8));
+    }
+}
+
+hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, int *inexact,
+                             hipStream_t st)
+{
+    const long long n = (long long)H * W;
+    const int bx = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3(bx), dim3(256), 0, st, img, H, W, pairs, inexact);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ init ---------
 // depth = exp(rand*(ln dmax - ln dmin) + ln dmin); normal = normalize(randn*0.3,
 // randn*0.3, -1); best_cost = +inf   (mvs_patchmatch.py:268-284)
@@ -446,9 +484,9 @@ __global__ __launch_bounds__(256) void pm_init_kernel(const Job *__restrict__ jo
                                                       float *__restrict__ normal,
                                                       float *__restrict__ cost)
 {
-    const Job &job = jobs[blockIdx.y];
-    const StreamKey key = stream_key(seed, job.stream_view, 0u);
-    const long long base = job.slot * HW;
+    const JobCP job = (JobCP)(jobs + blockIdx.y);
+    const StreamKey key = stream_key(seed, job->stream_view, 0u);
+    const long long base = job->slot * HW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW;
          i += (long long)gridDim.x * blockDim.x) {
         const uint32_t h0 = pixel_hash((uint32_t)i, key);
@@ -486,13 +524,19 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
 template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
-    hipLaunchKernelGGL((pm_step_kernel<K, S>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    if (a.pairs)
+        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    else
+        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
     return hipGetLastError();
 }
 template <int K, int S>
 static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
 {
-    hipLaunchKernelGGL((plane_sweep_kernel<K, S>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    if (a.pairs)
+        hipLaunchKernelGGL((plane_sweep_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    else
+        hipLaunchKernelGGL((plane_sweep_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
     return hipGetLastError();
 }
 

@@ -114,8 +114,12 @@ class Engine:
     def timing(self):
         t = Timing()
         self._chk(self._lib.amvs_get_timing(self._h, C.byref(t)))
-        return {"sweep_ms": t.sweep_ms, "confidence_ms": t.confidence_ms,
+        return {"init_ms": t.init_ms, "sweep_ms": t.sweep_ms, "confidence_ms": t.confidence_ms,
                 "sweep_launches": t.sweep_launches, "pixel_hypotheses": t.pixel_hypotheses}
+
+    def sampling_mode(self):
+        """'u8-pairs' when the packed 8-bit maps are sampled, 'f32' otherwise."""
+        return "u8-pairs" if self._lib.amvs_sampling_mode(self._h) else "f32"
 
     # -- plane sweep -------------------------------------------------------
     def plane_sweep(self, ref, nbr_ids, depths, patch_size, thresh):

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Benchmark of the PatchMatch-MVS sweep on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one complete PatchMatch sweep (init, 8 x (2 propagation + 8 refinement) cost
+evaluations, confidence) over this rank's batch of reference views, with every image already
+resident in HBM.  Workload at N=1: BASELINE config 3 -- 16 views of 1920x1080, 7x7 NCC,
+4 sources, 8 iterations.  For N>1 every rank sweeps its own block of 16 views of a 16*N-view
+scene (weak scaling; all images replicated on every GPU because source sets cross shard
+boundaries) and the per-view maps (depth, normal, confidence: 20 B/pixel) are all-gathered
+over RCCL inside the timed step.
+
+Prints ONE JSON line (rank 0) with the throughput in Mpixel-hypotheses/s, the HBM-roofline
+figure of the dominant kernel (pm_step_kernel<7,4>, timed with HIP events on its own stream
+through amvs_get_timing) and -- at N=1 -- the CPU oracle timed on the host cores on a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(scene_small, patch, srcs, ref, depth_min, depth_max, evals_target_s=15.0):
+    """Time the CPU oracle (oracle/amvs_oracle.c, OpenMP over the host cores) on a bounded
+    sample: one 1080p reference view, 1 iteration x (2 propagation + n refinement) evaluations."""
+    from oracle import oracle
+    oracle.set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or 16)   # the box's CPU share
+    K = scene_small.camera.K.astype(np.float32)
+    ctx = oracle.ViewContext(K, scene_small.grays[ref], scene_small.poses[ref].R, scene_small.poses[ref].t,
+                             [scene_small.grays[i] for i in srcs], [scene_small.poses[i].R for i in srcs],
+                             [scene_small.poses[i].t for i in srcs], patch)
+    H, W = scene_small.grays[ref].shape
+    t0 = time.time()
+    ctx.patchmatch(0, 0, depth_min, depth_max, 1, ref)            # init + confidence only: warm
+    t_fixed = time.time() - t0
+    iters, samples = 2, 8
+    t0 = time.time()
+    ctx.patchmatch(iters, samples, depth_min, depth_max, 1, ref)
+    dt = time.time() - t0 - t_fixed
+    n_hyp = H * W * iters * (2 + samples)
+    return {"value": n_hyp / max(dt, 1e-9) / 1e6, "unit": "Mpx-hyp/s", "cores": oracle.num_threads(),
+            "kind": "port",
+            "sample": f"1 of the 16 views at {W}x{H}, {iters} iterations x (2+{samples}) evaluations = "
+                      f"{n_hyp/1e6:.1f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--views-per-gpu", type=int, default=16)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--patch", type=int, default=7)
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import amvs
+    from amvs.engine import make_pm_params
+    from amvs.parallel import allgather_packed, shard
+    from amvs.synthetic import make_scene
+
+    H, W, vpg = args.height, args.width, args.views_per_gpu
+    n_views = vpg * world
+    # synthetic calibrated scene rendered on the GPU (data generation, outside the timed region)
+    sc = make_scene(n_views, H, W, seed=1234, device=str(dev))
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = {r: pm._select_source_views(r, ids, sc.poses, k=4) for r in ids}
+    mine = shard(n_views, rank, world)
+
+    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=local)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
+    # 8-bit images, as every real input is (cvtColor(...).astype(float32)/255,
+    # mvs_patchmatch.py:177): gray = code/255 in IEEE float32 through a host-built table
+    lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(dev)
+    for i in ids:
+        codes = torch.round(torch.from_numpy(sc.grays[i]).to(dev) * 255.0).clamp(0, 255).long()
+        g = lut[codes].contiguous()
+        sc.grays[i] = g.cpu().numpy()
+        eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
+        torch.cuda.synchronize()
+    params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows)
+    n_loc = len(mine)
+    depth = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
+    normal = torch.empty((n_loc, H, W, 3), dtype=torch.float32, device=dev)
+    conf = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
+    refs = list(mine)
+    srcs = [sources[r] for r in refs]
+
+    def step():
+        eng.patchmatch_device(refs, srcs, params, 42, depth.data_ptr(), normal.data_ptr(), conf.data_ptr())
+        if world > 1:
+            with torch.cuda.stream(stream):
+                packed = torch.cat([depth.reshape(n_loc, -1), normal.reshape(n_loc, -1),
+                                    conf.reshape(n_loc, -1)], dim=1)
+                allgather_packed(packed, n_views, 5 * H * W)
+        eng.sync()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    sweep_ms = conf_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        step()
+        t = eng.timing()
+        sweep_ms += t["sweep_ms"]
+        conf_ms += t["confidence_ms"]
+        launches += t["sweep_launches"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
+    value = n_hyp_step * args.steps / elapsed / 1e6
+    S = 4
+    bytes_per_hyp = 4 * S + 44                       # 60 B at S=4
+    launch_ms = sweep_ms / max(launches, 1)
+    algo_bytes_launch = bytes_per_hyp * n_loc * H * W
+    achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "Mpixel-hypotheses/s (PatchMatch sweep)",
+            "value": round(value, 1),
+            "unit": "Mpx-hyp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: {vpg}-view {W}x{H} PatchMatch MVS per GPU, "
+                                   f"{args.iters} iters x (2+{args.samples}) hypotheses, {args.patch}x{args.patch} NCC, "
+                                   f"{S} sources" + (f"; {n_views}-view scene, RCCL all-gather of maps" if world > 1 else ""),
+                       "views_per_gpu": vpg, "width": W, "height": H, "patch": args.patch,
+                       "iters": args.iters, "samples": args.samples, "sources": S,
+                       "sampling": eng.sampling_mode(), "tile_rows": args.tile_rows,
+                       "pixel_hypotheses_per_step": n_hyp_step},
+            "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
+            "confidence_ms_per_step": round(conf_ms / args.steps, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ref = n_views // 2
+            out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources[ref], ref, sc.depth_min, sc.depth_max)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,9 +52,10 @@ typedef struct {
 /* Per-call device timing of the sweep kernels (HIP events on the context
  * stream; used by bench.py for the roofline figure).                            */
 typedef struct {
-    double  sweep_ms;         /* init + propagation + refinement launches          */
+    double  init_ms;          /* initialisation launch                             */
+    double  sweep_ms;         /* propagation + refinement launches (pm_step)       */
     double  confidence_ms;    /* confidence launch                                 */
-    int64_t sweep_launches;
+    int64_t sweep_launches;   /* number of pm_step launches inside sweep_ms        */
     int64_t pixel_hypotheses; /* n_ref * H * W * iters * (2 + samples)            */
 } amvs_timing;
 
@@ -88,6 +89,11 @@ int amvs_patchmatch_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const i
                            int n_src, const amvs_pm_params *p, uint64_t seed,
                            void *depth_dev, void *normal_dev, void *conf_dev);
 int amvs_get_timing(const amvs_ctx *ctx, amvs_timing *out);
+/* 1 if the sweeps sample the packed 8-bit row-pair maps (every uploaded view is exactly
+ * code/255, as cvtColor(...).astype(float32)/255 yields, mvs_patchmatch.py:177), 0 if they
+ * sample the float32 maps.  Both give bit-identical results; AMVS_FORCE_F32_SAMPLING=1 in the
+ * environment at amvs_create selects the float32 path unconditionally.                     */
+int amvs_sampling_mode(const amvs_ctx *ctx);
 
 /* DenseStereoReconstructor._plane_sweep_torch (dense_stereo.py:222-316) for one
  * reference view: D depth planes, votes (ncc > thresh) & (z > 0.1) over n_nbr

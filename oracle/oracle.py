@@ -53,7 +53,11 @@ def lib():
                                           f32p, f32p, f32p]
         L.orc_plane_sweep.argtypes = [C.c_void_p, f32p, C.c_int, C.c_float, f32p, f32p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
         _lib = L
+        # a GPU box exposes every host core but grants a 16-CPU share: cap the OpenMP team
+        # (AMVS_ORACLE_THREADS overrides), tiny test images gain nothing from more
+        set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or min(os.cpu_count() or 1, 8))
     return _lib
 
 
@@ -204,6 +208,10 @@ def init_state(u, n0, n1, depth_min, depth_max):
     lib().orc_init_state(H * W, up, n0p, n1p, np.float32(log_max - log_min), np.float32(log_min),
                          d.ctypes.data_as(f32p), n.ctypes.data_as(f32p), c.ctypes.data_as(f32p))
     return d, n, c
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
 
 
 def num_threads():

@@ -1,0 +1,305 @@
+"""HIP kernels (through the C ABI) against the CPU oracle and the reference's golden vectors.
+
+Bar: BIT-EXACT against the oracle for depth, cost, confidence and normals (the kernels and the
+oracle use the same arithmetic order by construction); against the golden vectors captured
+from the reference the tolerances of tests/test_oracle_golden.py apply (box-filter summation
+order inside oneDNN is unobservable).
+"""
+import numpy as np
+import pytest
+
+from conftest import GoldenScene, assert_cost_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amvs_mod():
+    import amvs
+    return amvs
+
+
+@pytest.fixture(scope="module")
+def eng_a(scene_a, amvs_mod):
+    eng = scene_a.engine()
+    yield eng
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def eng_b(scene_b, amvs_mod):
+    eng = scene_b.engine()
+    yield eng
+    eng.close()
+
+
+def _eq(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{what}: {int((~same).sum())} of {same.size} elements differ " \
+                       f"(first at {np.argwhere(~same)[0]}: {a[~same][0]!r} vs {b[~same][0]!r})"
+
+
+# ------------------------------------------------------------------ primitives ----
+def test_rng_bit_exact(eng_a):
+    from oracle import oracle
+    for seed, view, draw, n in ((42, 0, 0, 5000), (2**40 + 17, 3, 9, 12345), (0, 31, 64, 777)):
+        u, nz = eng_a.rng_fill(seed, view, draw, n)
+        ou, onz = oracle.rng_fill(seed, view, draw, n)
+        _eq(u, ou, "uniform")
+        _eq(nz, onz, "normals")
+
+
+def test_init_state_bit_exact(eng_a, scene_a):
+    from oracle import oracle
+    d, n, c = eng_a.init_state(42, 2, scene_a.depth_min, scene_a.depth_max)
+    u, nz = oracle.rng_fill(42, 2, 0, scene_a.H * scene_a.W)
+    H, W = scene_a.H, scene_a.W
+    od, on, oc = oracle.init_state(u.reshape(H, W), nz[:, 0].reshape(H, W), nz[:, 1].reshape(H, W),
+                                   scene_a.depth_min, scene_a.depth_max)
+    _eq(d, od, "init depth")
+    _eq(n, on, "init normal")
+    _eq(c, oc, "init cost")
+
+
+@pytest.mark.parametrize("k", [5, 7, 11])
+def test_box_stats_bit_exact(eng_a, scene_a, k):
+    from oracle import oracle
+    for v in (0, 3):
+        m, var = eng_a.box_stats(v, k)
+        om, ovar = oracle.box_stats(scene_a.grays[v], k)
+        _eq(m, om, f"mean k{k}")
+        _eq(var, ovar, f"var k{k}")
+
+
+def _mixed_depth(scene, ref, seed):
+    rng = np.random.default_rng(seed)
+    d = np.exp(rng.uniform(np.log(scene.depth_min), np.log(scene.depth_max), (scene.H, scene.W))).astype(np.float32)
+    d[:, scene.W // 2:] = scene.gt_depth[ref][:, scene.W // 2:]
+    d[:5, :7] = np.float32(0.05)
+    d[-6:, -9:] = np.float32(400.0)
+    return d
+
+
+@pytest.mark.parametrize("k", [5, 7, 11])
+@pytest.mark.parametrize("srcs", [[1, 3, 0, 4], [3, 1], [0, 1, 4], [1, 3, 0, 4, 2][:4]])
+def test_eval_cost_bit_exact(eng_a, scene_a, k, srcs):
+    ref = 2
+    srcs = [s for s in srcs if s != ref]
+    depth = _mixed_depth(scene_a, ref, 5)
+    got = eng_a.eval_cost(ref, srcs, k, depth)
+    want = scene_a.oracle_ctx(ref, srcs, k).patch_cost(depth)
+    assert np.isposinf(want).any()
+    _eq(got, want, f"cost k{k} S{len(srcs)}")
+
+
+def test_eval_cost_vs_reference_golden(eng_a, scene_a):
+    g = load_golden("g03_patch_cost")
+    for k in (7, 11):
+        for tag in ("s4", "s2"):
+            srcs = list(g["srcs4"] if tag == "s4" else g["srcs2"])
+            got = eng_a.eval_cost(int(g["ref"]), srcs, k, g["depth"])
+            assert_cost_close(got, g[f"cost_k{k}_{tag}"], 1e-4, f"k{k} {tag}")
+
+
+def test_confidence_bit_exact_and_golden(eng_a, scene_a):
+    g = load_golden("g07_confidence")
+    ref, srcs, k = int(g["ref"]), list(g["srcs"]), int(g["patch"])
+    got = eng_a.confidence(ref, srcs, k, g["depth"])
+    _eq(got, scene_a.oracle_ctx(ref, srcs, k).confidence(g["depth"]), "confidence")
+    assert np.mean(got != g["confidence"]) < 2e-3
+
+
+@pytest.mark.parametrize("off", [(1, 0), (0, 1), (-1, 0), (0, -1)])
+def test_propagate_step_bit_exact(eng_a, scene_a, off):
+    g = load_golden("g04_propagate")
+    ref, srcs, k = int(g["ref"]), list(g["srcs"]), int(g["patch"])
+    got = eng_a.propagate_step(ref, srcs, k, g["depth"], g["normal"], g["cost"], off[0], off[1], scene_a.depth_min)
+    want = scene_a.oracle_ctx(ref, srcs, k).propagate_step(g["depth"], g["normal"], g["cost"], off[0], off[1],
+                                                           scene_a.depth_min)
+    for a, b, name in zip(got, want, ("depth", "normal", "cost")):
+        _eq(a, b, f"propagate {off} {name}")
+    assert (got[0] != g["depth"]).mean() > 0.01
+
+
+def test_propagation_vs_reference_golden(eng_a, scene_a):
+    g = load_golden("g04_propagate")
+    ref, srcs, k = int(g["ref"]), list(g["srcs"]), int(g["patch"])
+    for tag, offs in (("even", [(1, 0), (0, 1)]), ("odd", [(-1, 0), (0, -1)])):
+        d, n, c = g["depth"], g["normal"], g["cost"]
+        for oy, ox in offs:
+            d, n, c = eng_a.propagate_step(ref, srcs, k, d, n, c, oy, ox, scene_a.depth_min)
+        assert np.mean(d == g[f"depth_{tag}"]) >= 0.995
+
+
+@pytest.mark.parametrize("it", [0, 2])
+def test_refine_step_bit_exact(eng_a, scene_a, it):
+    from oracle import oracle
+    g = load_golden("g05_refine")
+    ref, srcs, k, seed = int(g["ref"]), list(g["srcs"]), int(g["patch"]), int(g["seed"])
+    dr = np.float32((scene_a.depth_max - scene_a.depth_min) * 0.5 ** it)
+    nr = np.float32(0.5 * 0.5 ** it)
+    ctx = scene_a.oracle_ctx(ref, srcs, k)
+    d, n, c = g["depth"], g["normal"], g["cost"]
+    od, on, oc = d, n, c
+    for s in range(2):
+        draw = 1 + it * 2 + s
+        d, n, c = eng_a.refine_step(ref, srcs, k, d, n, c, seed, ref, draw, dr, nr,
+                                    scene_a.depth_min, scene_a.depth_max)
+        u, nz = oracle.rng_fill(seed, ref, draw, scene_a.H * scene_a.W)
+        od, on, oc = ctx.refine_step(od, on, oc, u, nz, dr, nr, scene_a.depth_min, scene_a.depth_max)
+        _eq(d, od, f"refine it{it} s{s} depth")
+        _eq(c, oc, f"refine it{it} s{s} cost")
+        _eq(n, on, f"refine it{it} s{s} normal")
+    assert np.all(c <= g["cost"])                                 # best cost never increases
+    assert np.mean(d == g[f"depth_it{it}"]) >= 0.995              # reference golden
+
+
+# ------------------------------------------------------------------ end to end ----
+def test_patchmatch_bit_exact_vs_oracle_and_golden(eng_b, scene_b, amvs_mod):
+    from amvs.engine import make_pm_params
+    g = load_golden("g06_patchmatch_e2e")
+    refs = [int(r) for r in g["refs"]]
+    srcs = [list(g[f"srcs_{r}"]) for r in refs]
+    p = make_pm_params(int(g["patch"]), int(g["iters"]), int(g["samples"]), scene_b.depth_min, scene_b.depth_max)
+    depth, normal, conf = eng_b.patchmatch(refs, srcs, p, int(g["seed"]))      # both views in one batch
+    t = eng_b.timing()
+    assert t["sweep_launches"] == 3 * (2 + 4) and t["sweep_ms"] > 0
+    assert t["pixel_hypotheses"] == 2 * scene_b.H * scene_b.W * 3 * 6
+    for i, r in enumerate(refs):
+        od, on, oc = scene_b.oracle_ctx(r, srcs[i], int(g["patch"])).patchmatch(
+            int(g["iters"]), int(g["samples"]), scene_b.depth_min, scene_b.depth_max, int(g["seed"]), r)
+        _eq(depth[i], od, f"view {r} depth")
+        _eq(conf[i], oc, f"view {r} confidence")
+        _eq(normal[i], on, f"view {r} normal")
+        # reference: 1e-3 relative on identical RNG streams, as a pixel fraction
+        rel = np.abs(depth[i] - g[f"depth_{r}"]) / g[f"depth_{r}"]
+        assert np.mean(rel <= 1e-3) >= 0.97
+        hist_got = np.bincount(conf[i].astype(int).ravel(), minlength=5) / conf[i].size
+        hist_ref = np.bincount(g[f"confidence_{r}"].astype(int).ravel(), minlength=5) / conf[i].size
+        assert np.abs(hist_got - hist_ref).max() < 0.02
+
+
+def test_plane_sweep_bit_exact_and_golden(scene_c):
+    g = load_golden("g11_plane_sweep")
+    eng = scene_c.engine()
+    try:
+        ref, nbrs, k = int(g["ref"]), list(g["nbrs"]), int(g["patch"])
+        depths = g["depths"].astype(np.float32)
+        d, conf = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
+        od, oc = scene_c.oracle_ctx(ref, nbrs, k).plane_sweep(depths, float(g["thresh"]))
+        _eq(d, od, "sweep depth")
+        _eq(conf, oc, "sweep confidence")
+        assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("shape", [(33, 59), (70, 117), (41, 200)])
+def test_ragged_shapes_bit_exact(amvs_mod, shape):
+    """Widths that are not multiples of the strip width, heights not multiples of the strip rows."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    H, W = shape
+    sc = make_scene(4, H, W, seed=H)
+    K = sc.camera.K.astype(np.float32)
+    with amvs_mod.Engine(H, W, 4, K) as eng:
+        for i in range(4):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        for k in (5, 11):
+            p = make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max)
+            depth, normal, conf = eng.patchmatch([1], [[0, 2, 3]], p, 9)
+            ctx = oracle.ViewContext(K, sc.grays[1], sc.poses[1].R, sc.poses[1].t,
+                                     [sc.grays[i] for i in (0, 2, 3)], [sc.poses[i].R for i in (0, 2, 3)],
+                                     [sc.poses[i].t for i in (0, 2, 3)], k)
+            od, on, oc = ctx.patchmatch(2, 2, sc.depth_min, sc.depth_max, 9, 1)
+            _eq(depth[0], od, f"{shape} k{k} depth")
+            _eq(conf[0], oc, f"{shape} k{k} conf")
+            _eq(normal[0], on, f"{shape} k{k} normal")
+
+
+# --------------------------------------------------- full-size, size-independent ----
+def test_full_size_invariants(amvs_mod):
+    """1920x1080 (BASELINE config 3 resolution): results do not depend on the strip height,
+    on batching, or on the run; best cost is monotone; the ground-truth depth scores far
+    better than a random one."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    H, W, n = 1080, 1920, 5
+    sc = make_scene(n, H, W, seed=21)
+    K = sc.camera.K.astype(np.float32)
+    with amvs_mod.Engine(H, W, n, K) as eng:
+        for i in range(n):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        srcs = {2: [1, 3, 0, 4], 1: [0, 2, 3, 4]}
+        base = None
+        for tile_rows in (64, 8, 24):
+            p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max, tile_rows=tile_rows)
+            out = eng.patchmatch([2], [srcs[2]], p, 5)
+            if base is None:
+                base = out
+            else:
+                for a, b, name in zip(out, base, ("depth", "normal", "confidence")):
+                    _eq(a, b, f"tile_rows {tile_rows} {name}")
+        p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max)
+        both = eng.patchmatch([1, 2], [srcs[1], srcs[2]], p, 5)
+        for a, b, name in zip(both, base, ("depth", "normal", "confidence")):
+            _eq(a[1], b[0], f"batched {name}")
+        assert np.isfinite(base[0]).all() and base[0].min() >= np.float32(sc.depth_min) \
+            and base[0].max() <= np.float32(sc.depth_max)
+        assert eng.sampling_mode() == "f32"            # rendered floats are not 8-bit exact
+        # unit normals, or the exact zero normal that propagation pulls in from beyond the
+        # image border (F.pad of the normal map, mvs_patchmatch.py:432-442)
+        nrm = np.linalg.norm(base[1], axis=-1)
+        assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
+        assert np.mean(nrm == 0) < 0.01
+        c_gt = eng.eval_cost(2, srcs[2], 7, sc.depths[2])
+        c_rand = eng.eval_cost(2, srcs[2], 7, np.full((H, W), sc.depth_max * 0.9, np.float32))
+        inner = (slice(100, -100), slice(200, -200))
+        assert np.nanmean(c_gt[inner][np.isfinite(c_gt[inner])]) < 0.1
+        assert np.nanmean(c_rand[inner][np.isfinite(c_rand[inner])]) > 0.5
+        conf_gt = eng.confidence(2, srcs[2], 7, sc.depths[2])
+        assert np.mean(conf_gt[inner] >= 3) > 0.9
+
+
+def test_packed_and_float_sampling_agree(scene_b, monkeypatch):
+    """8-bit scenes take the packed row-pair path; forcing the float32 path must not change
+    a single bit (and the golden scenes do exercise the packed path)."""
+    from amvs.engine import make_pm_params
+    p = make_pm_params(7, 2, 3, scene_b.depth_min, scene_b.depth_max)
+    eng = scene_b.engine()
+    assert eng.sampling_mode() == "u8-pairs"
+    fast = eng.patchmatch([1, 3], [[0, 2, 3, 4], [1, 2, 4, 0]], p, 11)
+    eng.close()
+    monkeypatch.setenv("AMVS_FORCE_F32_SAMPLING", "1")
+    eng = scene_b.engine()
+    assert eng.sampling_mode() == "f32"
+    slow = eng.patchmatch([1, 3], [[0, 2, 3, 4], [1, 2, 4, 0]], p, 11)
+    eng.close()
+    for a, b, name in zip(fast, slow, ("depth", "normal", "confidence")):
+        _eq(a, b, name)
+
+
+def test_non_8bit_images_use_float_path(amvs_mod):
+    from amvs.synthetic import make_scene
+    sc = make_scene(3, 40, 70, seed=2)
+    with amvs_mod.Engine(40, 70, 3, sc.camera.K.astype(np.float32)) as eng:
+        for i in range(3):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "f32"
+
+
+# ------------------------------------------------------------------ error paths ---
+def test_error_paths(eng_a, scene_a, amvs_mod):
+    from amvs._lib import AmvsError
+    d = scene_a.gt_depth[2]
+    with pytest.raises(AmvsError, match="patch_size"):
+        eng_a.eval_cost(2, [1, 3], 9, d)
+    with pytest.raises(AmvsError, match="n_src"):
+        eng_a.eval_cost(2, [1], 7, d)
+    with pytest.raises(AmvsError, match="not uploaded"):
+        eng_a.eval_cost(2, [1, 17], 7, d)
+    with pytest.raises(AmvsError):
+        amvs_mod.Engine(0, 10, 3, np.eye(3))
