@@ -45,6 +45,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "amvs_sampling_mode": (C.c_int, [C.c_void_p]),
+    "amvs_last_tile_rows": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,
                                    C.c_float, f32p, f32p]),
     "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,

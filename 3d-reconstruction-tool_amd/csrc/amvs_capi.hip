@@ -30,7 +30,7 @@ struct Stats {
 }  // namespace
 
 struct amvs_ctx {
-    int device = 0, H = 0, W = 0, n_views = 0;
+    int device = 0, H = 0, W = 0, n_views = 0, n_cu = 256;
     long long stride = 0;   // floats between images (H*W rounded up + tail padding)
     float K[9], Kinv[9];
     std::vector<std::array<float, 9>> R;
@@ -54,6 +54,7 @@ struct amvs_ctx {
     int cap_planes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int last_tile_rows = 0;
     bool timing_pending = false;
     amvs_timing timing{};
     std::string err;
@@ -175,20 +176,6 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
     return AMVS_OK;
 }
 
-int pick_tile_rows(const amvs_ctx *c, int patch, int n_jobs, int requested, int cap)
-{
-    if (requested > 0) return requested < cap ? requested : cap;
-    const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
-    // tallest strip that still gives the 256 CUs several waves per SIMD
-    const int cands[4] = {64, 32, 16, 8};
-    for (int th : cands) {
-        if (th > cap) continue;
-        const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
-        if (waves >= 8192) return th;
-    }
-    return 8;
-}
-
 // the packed maps can be used when every uploaded view quantised losslessly
 const uint16_t *usable_pairs(const amvs_ctx *c)
 {
@@ -196,6 +183,27 @@ const uint16_t *usable_pairs(const amvs_ctx *c)
     for (int v = 0; v < c->n_views; ++v)
         if (c->have[v] && !c->exact8[v]) return nullptr;
     return c->d_pairs;
+}
+
+// Rows per wave strip.  A strip re-samples 2*(patch/2) halo rows, so tall strips waste less;
+// but the launch runs in "rounds" of (CUs x resident waves) strips and a partly filled last
+// round idles the chip.  Pick the height that maximises  fill-of-last-round x useful-row share.
+int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap)
+{
+    if (requested > 0) return requested < cap ? requested : cap;
+    const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
+    const int slots = c->n_cu * amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr);
+    const int halo = 2 * (patch / 2);
+    int best = 8;
+    double best_eff = -1.0;
+    for (int th = 8; th <= 128 && th <= cap; th += 2) {
+        const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
+        const double rounds = (double)waves / slots;
+        const double fill = rounds / std::ceil(rounds);
+        const double eff = fill * th / (double)(th + halo);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = th; }
+    }
+    return best;
 }
 
 amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
@@ -257,7 +265,7 @@ int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src))) return rc;
     if ((rc = ensure_stats(c, patch))) return rc;
     o.c = c; o.patch = patch; o.n_src = n_src; o.hw = (size_t)c->H * c->W;
-    o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, 1, 0, 64));
+    o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64));
     set_io(o.a, c, 0);
     return AMVS_OK;
 }
@@ -320,6 +328,11 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     };
     hipError_t e;
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && ncu > 0)
+            c->n_cu = ncu;
+    }
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
@@ -430,7 +443,8 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if ((rc = ensure_stats(c, p->patch_size))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
-    const int TH = pick_tile_rows(c, p->patch_size, n_ref, p->tile_rows, 1 << 20);
+    const int TH = pick_tile_rows(c, p->patch_size, n_src, n_ref, p->tile_rows, 1 << 20);
+    c->last_tile_rows = TH;
     amvs::StepArgs a = base_args(c, p->patch_size, n_ref, TH);
     a.depth_min = p->depth_min; a.depth_max = p->depth_max;
     a.seed = seed;
@@ -526,6 +540,8 @@ int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
 
 int amvs_sampling_mode(const amvs_ctx *c) { return c && usable_pairs(c) ? 1 : 0; }
 
+int amvs_last_tile_rows(const amvs_ctx *c) { return c ? c->last_tile_rows : 0; }
+
 int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
                             const float *depths, int D, int patch_size, float thresh, void *depth_dev,
                             void *conf_dev)
@@ -547,7 +563,8 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     amvs::SweepArgs a{};
     a.H = c->H; a.W = c->W;
-    a.TH = pick_tile_rows(c, patch_size, n_ref, 0, AMVS_SWEEP_MAX_TH);
+    a.TH = pick_tile_rows(c, patch_size, n_nbr, n_ref, 0, AMVS_SWEEP_MAX_TH);
+    c->last_tile_rows = a.TH;
     a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
     a.tiles_y = (c->H + a.TH - 1) / a.TH;
     a.n_jobs = n_ref; a.D = D;

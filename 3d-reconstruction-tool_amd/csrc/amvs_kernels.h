@@ -52,6 +52,7 @@ struct SweepArgs {
 
 bool patch_supported(int K);
 int strip_out_width(int K);
+int step_waves_per_cu(int K, int S, bool u8);
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,

@@ -547,8 +547,28 @@ static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
     case 4: return FN<K, 4>(__VA_ARGS__);                           \
     case 5: return FN<K, 5>(__VA_ARGS__);                           \
     case 6: return FN<K, 6>(__VA_ARGS__);                           \
-    default: return hipErrorInvalidValue;                           \
+    default: return decltype(FN<K, 2>(__VA_ARGS__))(1);             \
     }
+
+template <int K, int S>
+static int step_occupancy_ks(bool u8)
+{
+    int n = 0;
+    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true>, AMVS_WAVE, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false>, AMVS_WAVE, 0);
+    return e == hipSuccess && n > 0 ? n : 8;
+}
+
+// resident single-wave blocks per CU of the sweep kernel (register-limited)
+int step_waves_per_cu(int K, int S, bool u8)
+{
+    switch (K) {
+    case 5: AMVS_FOR_S(5, step_occupancy_ks, u8)
+    case 7: AMVS_FOR_S(7, step_occupancy_ks, u8)
+    case 11: AMVS_FOR_S(11, step_occupancy_ks, u8)
+    default: return 8;
+    }
+}
 
 bool patch_supported(int K) { return K == 5 || K == 7 || K == 11; }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }

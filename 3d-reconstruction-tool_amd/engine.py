@@ -121,6 +121,9 @@ class Engine:
         """'u8-pairs' when the packed 8-bit maps are sampled, 'f32' otherwise."""
         return "u8-pairs" if self._lib.amvs_sampling_mode(self._h) else "f32"
 
+    def last_tile_rows(self):
+        return int(self._lib.amvs_last_tile_rows(self._h))
+
     # -- plane sweep -------------------------------------------------------
     def plane_sweep(self, ref, nbr_ids, depths, patch_size, thresh):
         nbr, nbrp = _ids(nbr_ids)

@@ -178,7 +178,7 @@ def main():
                                    f"{S} sources" + (f"; {n_views}-view scene, RCCL all-gather of maps" if world > 1 else ""),
                        "views_per_gpu": vpg, "width": W, "height": H, "patch": args.patch,
                        "iters": args.iters, "samples": args.samples, "sources": S,
-                       "sampling": eng.sampling_mode(), "tile_rows": args.tile_rows,
+                       "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(),
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -94,6 +94,8 @@ int amvs_get_timing(const amvs_ctx *ctx, amvs_timing *out);
  * sample the float32 maps.  Both give bit-identical results; AMVS_FORCE_F32_SAMPLING=1 in the
  * environment at amvs_create selects the float32 path unconditionally.                     */
 int amvs_sampling_mode(const amvs_ctx *ctx);
+/* Rows per wave strip the last sweep used (amvs_pm_params.tile_rows, or the automatic choice). */
+int amvs_last_tile_rows(const amvs_ctx *ctx);
 
 /* DenseStereoReconstructor._plane_sweep_torch (dense_stereo.py:222-316) for one
  * reference view: D depth planes, votes (ncc > thresh) & (z > 0.1) over n_nbr
