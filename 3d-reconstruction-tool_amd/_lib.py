@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamvs.so")
+# AMVS_LIB selects an alternative build of the same ABI (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
 SUPPORTED_PATCH_SIZES = (5, 7, 11)

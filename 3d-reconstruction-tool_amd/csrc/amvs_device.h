@@ -189,25 +189,44 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
     return c;
 }
 
-// Project a world point into a source view and sample it bilinearly
-// (mvs_patchmatch.py:351-377: project, bounds test, grid_sample bilinear / zeros /
-// align_corners=True, restated bit-exactly against ATen's CPU kernel).  The projection is
+// Sampling a source view is split into three phases so that a row can issue the gathers of
+// ALL its sources back to back (one exposed memory latency per row instead of one per source):
+//   sample_geom   project + bounds test + bilinear weights + addresses       (pure VALU)
+//   sample_load   the gather(s)                                              (VMEM)
+//   sample_finish decode + masked 4-tap fma chain                            (LDS + VALU)
+//
+// Reference: mvs_patchmatch.py:351-377 (project, bounds test, grid_sample bilinear / zeros /
+// align_corners=True), restated bit-exactly against ATen's CPU kernel.  The projection is
 // valid when z > 0.1 and lo <= u < hix, lo <= v < hiy (patch bounds :362-363, image bounds
 // :516-517, or -inf/+inf for the plane sweep, which only tests z: dense_stereo.py:280,303).
-// `live` masks lanes whose pixel is outside the image: they issue no loads and return 0
-// (the zero padding of the box filter).
+// `live` masks lanes whose pixel is outside the image: their gather reads element 0 and the
+// sample is 0 (the zero padding of the box filter).
 //
-// U8 = false: `img` is the float32 gray map; four dword gathers over two image rows.
-// U8 = true : `img` is the packed 8-bit row-pair map (ushort (y,x) = code(y,x) |
+// U8 = false: the source is the float32 gray map; four dword gathers over two image rows.
+// U8 = true : the source is the packed 8-bit row-pair map (ushort (y,x) = code(y,x) |
 //             code(y+1,x) << 8) of an image whose every pixel equals code/255 exactly (what
 //             cvtColor(...).astype(float32)/255 produces, mvs_patchmatch.py:177).  One
 //             2-byte-aligned dword gather fetches the whole 2x2 footprint; codes are decoded
 //             through the 256-entry table `lut` in LDS (lut[c] = (float)c / 255.0f), so the tap
 //             values are bit-identical to the float32 map's.
+template <bool U8> struct TapGeom;
+template <> struct TapGeom<true> {
+    float nw, ne, sw, se;
+    int off;            // ushort index of the 4-byte read
+    uint32_t sel;       // [4:0] left-column shift, [12:8] right-column shift, [20:16] bottom-row
+                        // shift, [27:24] tap masks (t00,t01,t10,t11)
+};
+template <> struct TapGeom<false> {
+    float nw, ne, sw, se;
+    int o00, o01, o10, o11;
+    uint32_t sel;       // [27:24] tap masks
+};
+template <bool U8> struct TapRaw;
+template <> struct TapRaw<true> { uint32_t w; };
+template <> struct TapRaw<false> { float t00, t01, t10, t11; };
+
 template <bool U8, class KP, class RP, class TP>
-AMVS_DEV float project_sample(KP K, RP Rs, TP ts, const void *__restrict__ img,
-                              const float *lut, const SampleConsts &c, Vec3 Pw, bool live,
-                              bool &valid)
+AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3 Pw, bool live, bool &valid)
 {
     const int H = c.H, W = c.W;
     float p0 = __builtin_fmaf(Pw.z, Rs[2], __builtin_fmaf(Pw.y, Rs[1], Pw.x * Rs[0])) + ts[0];
@@ -218,7 +237,8 @@ AMVS_DEV float project_sample(KP K, RP Rs, TP ts, const void *__restrict__ img,
     float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];
-    valid = (z > 0.1f) && (u >= c.lo) && (u < c.hix) && (v >= c.lo) && (v < c.hiy);
+    // non-short-circuit '&': '&&' makes hipcc emit a branch per source here
+    valid = (z > 0.1f) & (u >= c.lo) & (u < c.hix) & (v >= c.lo) & (v < c.hiy);
     float gx = qdiv(2.0f * u, c.fw, c.rfw) - 1.0f;
     float gy = qdiv(2.0f * v, c.fh, c.rfh) - 1.0f;
     float ux = (gx + 1.0f) * c.hw2;
@@ -226,39 +246,72 @@ AMVS_DEV float project_sample(KP K, RP Rs, TP ts, const void *__restrict__ img,
     float x0 = __builtin_floorf(ux), y0 = __builtin_floorf(uy);
     float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
     float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
-    float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
-    bool x0ok = (x0 >= 0.0f) && (x0 <= c.fw), x1ok = (x1 >= 0.0f) && (x1 <= c.fw);
-    bool y0ok = (y0 >= 0.0f) && (y0 <= c.fh), y1ok = (y1 >= 0.0f) && (y1 <= c.fh);
-    float t00 = 0.0f, t01 = 0.0f, t10 = 0.0f, t11 = 0.0f;
+    TapGeom<U8> g;
+    g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
+    const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
+    const bool y0ok = (y0 >= 0.0f) & (y0 <= c.fh), y1ok = (y1 >= 0.0f) & (y1 <= c.fh);
+    uint32_t sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
+                   ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
     const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
-    if (U8) {
-        // clamped base keeps the 4-byte read inside the row; which bytes are the left /
-        // right column and the top / bottom row follows from where the clamp moved it
+    if constexpr (U8) {
+        // clamped base keeps the 4-byte read inside the row; which bytes are the left / right
+        // column and the top / bottom row follows from where the clamp moved it
         const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
-        uint32_t w = 0u;
-        if (live) __builtin_memcpy(&w, (const char *)img + 2 * (yb * W + xb), 4);
-        const uint32_t lsh = x0i > xb ? 16u : 0u;
-        const uint32_t rsh = x0i < xb ? 0u : 16u;
-        const uint32_t bsh = y0i < yb ? 0u : 8u;
-        t00 = lut[(w >> lsh) & 0xFFu];
-        t10 = lut[(w >> (lsh + bsh)) & 0xFFu];
-        t01 = lut[(w >> rsh) & 0xFFu];
-        t11 = lut[(w >> (rsh + bsh)) & 0xFFu];
+        g.off = live ? yb * W + xb : 0;
+        sel |= (x0i > xb ? 16u : 0u) | (x0i < xb ? 0u : 16u << 8) | (y0i < yb ? 0u : 8u << 16);
     } else {
-        const float *__restrict__ f = (const float *)img;
         const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
         const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
-        if (live) {
-            t00 = f[iy0 * W + ix0]; t01 = f[iy0 * W + ix1];
-            t10 = f[iy1 * W + ix0]; t11 = f[iy1 * W + ix1];
-        }
+        g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
+        g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
     }
-    t00 = (x0ok && y0ok) ? t00 : 0.0f;
-    t01 = (x1ok && y0ok) ? t01 : 0.0f;
-    t10 = (x0ok && y1ok) ? t10 : 0.0f;
-    t11 = (x1ok && y1ok) ? t11 : 0.0f;
-    float r = __builtin_fmaf(t11, se, __builtin_fmaf(t10, sw, __builtin_fmaf(t01, ne, t00 * nw)));
-    return live ? r : 0.0f;
+    g.sel = sel;
+    return g;
+}
+
+template <bool U8>
+AMVS_DEV TapRaw<U8> sample_load(const void *__restrict__ img, const TapGeom<U8> &g)
+{
+    TapRaw<U8> r;
+    if constexpr (U8) {
+#ifdef AMVS_ABLATE_L1_GATHER   // timing-only experiment: every gather hits a 2 KB window
+        __builtin_memcpy(&r.w, (const char *)img + 2 * (g.off & 1023), 4);
+#else
+        __builtin_memcpy(&r.w, (const char *)img + 2 * g.off, 4);
+#endif
+    } else {
+        const float *__restrict__ f = (const float *)img;
+        r.t00 = f[g.o00]; r.t01 = f[g.o01]; r.t10 = f[g.o10]; r.t11 = f[g.o11];
+    }
+    return r;
+}
+
+template <bool U8>
+AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const float *lut, bool live)
+{
+    float t00, t01, t10, t11;
+    if constexpr (U8) {
+        const uint32_t lsh = g.sel & 31u, rsh = (g.sel >> 8) & 31u, bsh = (g.sel >> 16) & 31u;
+#ifdef AMVS_ABL_NOLUT
+        t00 = (float)((r.w >> lsh) & 0xFFu) * 0.003921569f;
+        t10 = (float)((r.w >> (lsh + bsh)) & 0xFFu) * 0.003921569f;
+        t01 = (float)((r.w >> rsh) & 0xFFu) * 0.003921569f;
+        t11 = (float)((r.w >> (rsh + bsh)) & 0xFFu) * 0.003921569f;
+#else
+        t00 = lut[(r.w >> lsh) & 0xFFu];
+        t10 = lut[(r.w >> (lsh + bsh)) & 0xFFu];
+        t01 = lut[(r.w >> rsh) & 0xFFu];
+        t11 = lut[(r.w >> (rsh + bsh)) & 0xFFu];
+#endif
+    } else {
+        t00 = r.t00; t01 = r.t01; t10 = r.t10; t11 = r.t11;
+    }
+    t00 = (g.sel & (1u << 24)) ? t00 : 0.0f;
+    t01 = (g.sel & (1u << 25)) ? t01 : 0.0f;
+    t10 = (g.sel & (1u << 26)) ? t10 : 0.0f;
+    t11 = (g.sel & (1u << 27)) ? t11 : 0.0f;
+    float v = __builtin_fmaf(t11, g.se, __builtin_fmaf(t10, g.sw, __builtin_fmaf(t01, g.ne, t00 * g.nw)));
+    return live ? v : 0.0f;
 }
 
 // fill the 256-entry code -> gray table (one wave; entry c = (float)c / 255.0f, the

@@ -10,6 +10,8 @@ namespace amvs {
 
 // One reference view of a batch: its pose, its source views and where its state lives.
 struct Job {
+    float K[9], Kinv[9];    // shared intrinsics, copied per job so that the kernels fetch them with
+                            // the same in-loop scalar loads as the poses
     float Rref[9], tref[3];
     float Rs[AMVS_KMAX_SRC][9], ts[AMVS_KMAX_SRC][3];
     int ref_img;
@@ -20,13 +22,16 @@ struct Job {
 
 enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };
 
-struct StepArgs {
-    int H, W, TH, tiles_x, tiles_y, n_jobs;
+// where the images live (common head of StepArgs and SweepArgs)
+struct StepArgsBase {
     long long img_stride;                    // floats between consecutive images
-    float K[9], Kinv[9];
     const float *images, *mean1, *var1;      // [n_views][img_stride]
     const uint16_t *pairs;                   // packed 8-bit row-pair maps [n_views][pair_stride], or NULL
     long long pair_stride;
+};
+
+struct StepArgs : StepArgsBase {
+    int H, W, TH, tiles_x, tiles_y, n_jobs;
     const float *d_in, *c_in, *n_in;         // state read   [slot][H*W], normals [slot][H*W*3]
     float *d_out, *c_out, *n_out;            // state written
     float *aux;                              // MODE_EVAL: cost map, MODE_CONF: confidence
@@ -37,13 +42,8 @@ struct StepArgs {
     unsigned draw;
 };
 
-struct SweepArgs {
+struct SweepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs, D;
-    long long img_stride;
-    float K[9], Kinv[9];
-    const float *images, *mean1, *var1;
-    const uint16_t *pairs;
-    long long pair_stride;
     const float *depths;                     // [D] device
     float thresh;
     float *depth_out, *conf_out;             // [slot][H*W]

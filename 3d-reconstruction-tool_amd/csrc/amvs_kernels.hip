@@ -26,6 +26,28 @@ namespace amvs {
 // constant address space lets the compiler use scalar loads (s_load) for the poses.
 typedef const __attribute__((address_space(4))) Job *JobCP;
 
+// Opaque copy of a uniform pointer.  Loads through the result cannot be hoisted above this
+// point, so the row loops re-issue their scalar loads (s_load from the scalar cache) every
+// iteration instead of keeping ~90 pose / intrinsics values live and spilling SGPRs into VGPR
+// lanes (v_writelane / v_readlane), which cost 14 % of the VALU stream before.
+AMVS_DEV JobCP reload(JobCP p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#ifdef AMVS_ABLATE_ROW_RELOAD      // experiment: one reload per row instead of one per source
+#define AMVS_SRC_RELOAD(p) (p)
+#else
+#define AMVS_SRC_RELOAD(p) reload(p)
+#endif
+
+// timing-only ablations (results are wrong when any is defined)
+#ifdef AMVS_ABL_LOCALSTREAM
+#define AMVS_SIDX(i) ((i) & 1023)
+#else
+#define AMVS_SIDX(i) (i)
+#endif
+
 // contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
 AMVS_DEV int xcd_remap(int bid, int nblk)
 {
@@ -34,19 +56,160 @@ AMVS_DEV int xcd_remap(int bid, int nblk)
     return base + (bid >> 3);
 }
 
+// Sample all S sources of one pixel.  AMVS_PHASED: geometry of every source, then all gathers,
+// then decode (gathers issue back to back); default: source by source.  Same arithmetic either
+// way.  Measured on MI355X (16 views 1080p, k=7, S=4): source-by-source 26.9, phased 22.7 (128
+// VGPR) / 25.2 (147 VGPR) G px-hyp/s.
+template <int S, bool U8>
+AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
+                                 Vec3 Pw, bool live, float (&v)[S])
+{
+    unsigned okbits = 0u;
+    JobCP jr = job;
+#ifdef AMVS_PHASED
+    TapGeom<U8> tg[S];
+    TapRaw<U8> tr[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        bool ok;
+        jr = reload(jr);
+        tg[s] = sample_geom<U8>(jr->K, jr->Rs[s], jr->ts[s], sc, Pw, live, ok);
+        okbits |= ok ? (1u << s) : 0u;
+    }
+    jr = reload(jr);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const void *src = U8 ? (const void *)(a.pairs + jr->src_img[s] * a.pair_stride)
+                             : (const void *)(a.images + jr->src_img[s] * a.img_stride);
+        tr[s] = sample_load<U8>(src, tg[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
+#else
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        bool ok;
+        jr = AMVS_SRC_RELOAD(jr);
+        const TapGeom<U8> tg = sample_geom<U8>(jr->K, jr->Rs[s], jr->ts[s], sc, Pw, live, ok);
+        okbits |= ok ? (1u << s) : 0u;
+        const void *src = U8 ? (const void *)(a.pairs + jr->src_img[s] * a.pair_stride)
+                             : (const void *)(a.images + jr->src_img[s] * a.img_stride);
+        const TapRaw<U8> tr = sample_load<U8>(src, tg);
+        v[s] = sample_finish<U8>(tr, tg, lut, live);
+    }
+#endif
+    return okbits;
+}
+
+// ------------------------------------------------------------------ window sums --
+// k x k window sums of v, v*v and r*v for S sources at once, from the per-lane vertical rings.
+//   1. column sums, top -> bottom: plain sum for v, fma chains for v*v and r*v   (registers)
+//   2. row sums, right -> left:   sum_{j=K-1..0} c(lane+j)
+// Step 2 needs the column sums of the K-1 lanes to the right.  Two implementations with the
+// same summation order (and therefore the same bits):
+//   DPP  (default): K-1 `v_add_f32_dpp ... wave_shl:1` per sum, no LDS.  A DPP add costs 3x a
+//        plain add to issue on gfx950 (tools/shift_rate.hip) but needs no extra registers.
+//   LDS  (-DAMVS_HSUM_LDS): every lane stores its 3*S column sums as NV4 float4 at a lane stride
+//        of 12 (S<=4) or 20 (S>4) dwords -- conflict-free for ds_write_b128 / ds_read_b128 -- and
+//        reads its neighbours' with (K-1)*NV4 ds_read_b128 (one wave per workgroup and in-order
+//        LDS: no barrier).  Measured within +-1.5 % of DPP (26.9 vs 26.5 G px-hyp/s before the
+//        row pipeline) at ~25 more VGPRs, so it is not the default.
+template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
+
+template <int K, int S>
+AMVS_DEV void window_sums(const float (&ring_r)[K], const float (&ring_v)[S][K], float4 *hbuf, int lane,
+                          float (&bv)[S], float (&bvv)[S], float (&brv)[S])
+{
+    constexpr int NV4 = HSum<S>::NV4;
+    float cs[NV4 * 4];
+#pragma unroll
+    for (int i = 0; i < NV4 * 4; ++i) cs[i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float cv = ring_v[s][0];
+        float cvv = ring_v[s][0] * ring_v[s][0];
+        float crv = ring_r[0] * ring_v[s][0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) {
+            cv = cv + ring_v[s][i];
+            cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
+            crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
+        }
+        cs[3 * s] = cv; cs[3 * s + 1] = cvv; cs[3 * s + 2] = crv;
+    }
+#ifndef AMVS_HSUM_LDS
+    (void)hbuf; (void)lane;
+    float acc[NV4 * 4];
+#pragma unroll
+    for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
+#pragma unroll
+    for (int j = 1; j < K; ++j)
+#pragma unroll
+        for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
+#else
+    float4 *mine = hbuf + lane * NV4;
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) mine[q] = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+    __builtin_amdgcn_wave_barrier();
+    float acc[NV4 * 4];
+    // one float4 column group at a time: its K-1 neighbour reads are issued together, then
+    // summed right -> left
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) {
+        float4 t[K - 1];
+#pragma unroll
+        for (int j = 1; j < K; ++j) t[j - 1] = mine[j * NV4 + q];
+        float4 r = t[K - 2];
+#pragma unroll
+        for (int j = K - 2; j >= 1; --j) {
+            r.x += t[j - 1].x; r.y += t[j - 1].y; r.z += t[j - 1].z; r.w += t[j - 1].w;
+        }
+        acc[4 * q] = r.x + cs[4 * q]; acc[4 * q + 1] = r.y + cs[4 * q + 1];
+        acc[4 * q + 2] = r.z + cs[4 * q + 2]; acc[4 * q + 3] = r.w + cs[4 * q + 3];
+        // pin the sums here (LLVM otherwise sinks the adds to their first use and keeps every
+        // neighbour read live across the NCC epilogue)
+        asm volatile("" : "+v"(acc[4 * q]), "+v"(acc[4 * q + 1]), "+v"(acc[4 * q + 2]), "+v"(acc[4 * q + 3]));
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
+#pragma unroll
+    for (int s = 0; s < S; ++s) { bv[s] = acc[3 * s]; bvv[s] = acc[3 * s + 1]; brv[s] = acc[3 * s + 2]; }
+}
+
+// lanes beyond the strip read (K-1) entries past lane 63: keep them defined
+template <int K, int S>
+AMVS_DEV void window_sums_init(float4 *hbuf, int lane)
+{
+    constexpr int NV4 = HSum<S>::NV4;
+    if (lane < K - 1)
+#pragma unroll
+        for (int q = 0; q < NV4; ++q) hbuf[(AMVS_WAVE + lane) * NV4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ------------------------------------------------------------------ sweep step ---
 // One cost evaluation + select over a batch of reference views
 // (_compute_patch_cost / _spatial_propagation / _random_refinement /
 //  _compute_confidence, mvs_patchmatch.py:323-534).
+// minimum waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane)
+#ifndef AMVS_MIN_WAVES_BIAS
+#define AMVS_MIN_WAVES_BIAS 0
+#endif
+constexpr int min_waves(int K, int S)
+{
+    return ((S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_MIN_WAVES_BIAS;
+}
+
 template <int K, int S, bool U8>
-__global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
+__global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(const StepArgs a)
 {
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
     __shared__ float lut[256];
+    __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
 
     const int lane = threadIdx.x;
+    window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
@@ -97,48 +260,44 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
 #pragma unroll
     for (int i = 0; i <= HALF; ++i) { hist_ok[i] = 0u; hist_h0[i] = 0u; }
 
+    // The candidate of pixel (y,x) is read at (y+oy, x+ox): the neighbour for a propagation step
+    // (mvs_patchmatch.py:431-441), the pixel itself ((0,0)) for every other mode.  All loads use
+    // clamped indices (dead lanes read element 0), so there is no branch in the load path.
+    //
+    // Measured alternatives that did NOT pay on MI355X (16 views 1080p, k=7, S=4):
+    // issuing the S gathers of a row together (-15 %: +24 VGPRs), software-pipelining the row
+    // loop by one row (requests of row r+1 behind the epilogue of row r: -2 %, +60 VGPRs).
+    // Timing-only ablations show why: with every load served from L1 and no stores the launch
+    // still takes 82 % of its time -- the kernel is bound by instruction issue, not by memory.
+    const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
+    const int noff = oy * W + ox;
+
     for (int r = 0; r < rows; ++r) {
         const int yr = y0 - HALF + r;
-        const bool live = col_in && (unsigned)yr < (unsigned)H;
+        const bool live = col_in & ((unsigned)yr < (unsigned)H);
+        const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
+        const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];
+        const float r_raw = ref[AMVS_SIDX(live ? pix : 0)];
 
         // ---- candidate depth of this (possibly halo) pixel ----
-        float dc = 1.0f;
-        uint32_t h0 = 0u;
-        if (live) {
-            if (mode == MODE_PROP) {
-                // pull from (y+oy, x+ox); outside the image the candidate is depth_min
-                // (F.pad value, mvs_patchmatch.py:431-441)
-                const int ny = yr + a.oy, nx = xr + a.ox;
-                const bool inb = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
-                dc = a.depth_min;
-                if (inb) dc = d_in[ny * W + nx];
-            } else {
-                dc = d_in[pix];
-                if (mode == MODE_REFINE) {
-                    // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
-                    h0 = pixel_hash((uint32_t)pix, key);
-                    float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
-                    float d = dc + delta;
-                    d = d < a.depth_min ? a.depth_min : d;
-                    d = d > a.depth_max ? a.depth_max : d;
-                    dc = d;
-                }
-            }
+        // outside the image the pulled candidate is depth_min (F.pad value)
+        float dc = inb ? d_raw : a.depth_min;
+        // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
+        const uint32_t h0 = pixel_hash((uint32_t)pix, key);
+        {
+            float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
+            float d = dc + delta;
+            d = d < a.depth_min ? a.depth_min : d;
+            d = d > a.depth_max ? a.depth_max : d;
+            dc = mode == MODE_REFINE ? d : dc;
         }
-        const float rv = live ? ref[pix] : 0.0f;
-        const Vec3 Pw = backproject(a.Kinv, job->Rref, job->tref, xr, yr, dc);
+        const float rv = live ? r_raw : 0.0f;
+        JobCP jr = reload(job);
+        const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
 
-        unsigned okbits = 0u;
         float v[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            bool ok;
-            const void *src = U8 ? (const void *)(a.pairs + job->src_img[s] * a.pair_stride)
-                                 : (const void *)(a.images + job->src_img[s] * a.img_stride);
-            v[s] = project_sample<U8>(a.K, job->Rs[s], job->ts[s], src, lut, sc, Pw, live, ok);
-            okbits |= ok ? (1u << s) : 0u;
-        }
+        const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
 
         // ---- push into the vertical rings ----
 #pragma unroll
@@ -160,35 +319,21 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
         // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
         const int yc = yr - HALF;
         const int xc = xr + HALF;
-        const bool outl = lane < OUTW && xc < W;
-        const int pc = yc * W + xc;
+        const bool outl = (lane < OUTW) & (xc < W);
+        const int pc = AMVS_SIDX(outl ? yc * W + xc : 0);
+        const float m1 = mean1[pc], v1 = var1[pc];
+        const float oldd = d_in[pc], oldc = c_in[pc];
         // the centre pixel was sampled by lane+HALF, HALF rows ago
         const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
-        float m1 = 0.0f, v1 = 0.0f;
-        if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
+
+        float bvs[S], bvvs[S], brvs[S];
+        window_sums<K, S>(ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
 
         float total = 0.0f, cnt = 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            // column sums top -> bottom (plain sum; fma chains for the products)
-            float cv = ring_v[s][0];
-            float cvv = ring_v[s][0] * ring_v[s][0];
-            float crv = ring_r[0] * ring_v[s][0];
-#pragma unroll
-            for (int i = 1; i < K; ++i) {
-                cv = cv + ring_v[s][i];
-                cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
-                crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
-            }
-            // row sums right -> left: a_j(i) = a_{j-1}(i+1) + c(i)
-            float bv = cv, bvv = cvv, brv = crv;
-#pragma unroll
-            for (int j = 1; j < K; ++j) {
-                bv = wave_shl1(bv) + cv;
-                bvv = wave_shl1(bvv) + cvv;
-                brv = wave_shl1(brv) + crv;
-            }
+            const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
             // _ncc_cost (mvs_patchmatch.py:403-411)
             const float mean2 = bv * INV_AREA;
             const float var2 = bvv * INV_AREA - mean2 * mean2;
@@ -196,16 +341,18 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
             const float ncc = cov / (__builtin_sqrtf(v1 * var2) + 1e-8f);
             const float cost = 1.0f - ncc;
             const bool oks = (okc >> s) & 1u;
-            if (mode == MODE_CONF) {
-                // consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
-                const float ncc2 = 1.0f - cost;
-                if (oks && ncc2 > 0.6f) cnt += 1.0f;
-            } else if (oks) {                      // :383-384
-                total = total + cost;
-                cnt += 1.0f;
-            }
+            // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
+            const float ncc2 = 1.0f - cost;
+            const bool hit = mode == MODE_CONF ? (oks & (ncc2 > 0.6f)) : oks;
+            // cost: total += where(valid, cost, 0); count += valid   (:383-384)
+            total = (hit & (mode != MODE_CONF)) ? total + cost : total;
+            cnt = hit ? cnt + 1.0f : cnt;
         }
+#ifdef AMVS_ABL_NOSTORE
+        if (!(outl & (cnt > 1e30f))) continue;
+#else
         if (!outl) continue;
+#endif
 
         if (mode == MODE_CONF) { aux[pc] = cnt; continue; }
 
@@ -215,19 +362,16 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_kernel(const StepArgs a)
         if (mode == MODE_EVAL) { aux[pc] = newc; continue; }
 
         // ---- select (mvs_patchmatch.py:452-455 / :486-489) ----
-        const float oldd = d_in[pc];
-        const float oldc = c_in[pc];
-        float nx0 = n_in[3 * pc], nx1 = n_in[3 * pc + 1], nx2 = n_in[3 * pc + 2];
+        const float nx0 = n_in[3 * pc], nx1 = n_in[3 * pc + 1], nx2 = n_in[3 * pc + 2];
         float candd, cn0, cn1, cn2;
         if (mode == MODE_PROP) {
-            const int ny = yc + a.oy, nx = xc + a.ox;
-            const bool inb = (unsigned)ny < (unsigned)H && (unsigned)nx < (unsigned)W;
-            candd = a.depth_min; cn0 = 0.0f; cn1 = 0.0f; cn2 = 0.0f;    // zero-padded normal
-            if (inb) {
-                const int pn = ny * W + nx;
-                candd = d_in[pn];
-                cn0 = n_in[3 * pn]; cn1 = n_in[3 * pn + 1]; cn2 = n_in[3 * pn + 2];
-            }
+            // out-of-image neighbour: depth_min and a zero normal (F.pad, :431-442)
+            const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
+            const int pn = inb_c ? pc + noff : 0;
+            const float nb_d = d_in[pn];
+            const float nb0 = n_in[3 * pn], nb1 = n_in[3 * pn + 1], nb2 = n_in[3 * pn + 2];
+            candd = inb_c ? nb_d : a.depth_min;
+            cn0 = inb_c ? nb0 : 0.0f; cn1 = inb_c ? nb1 : 0.0f; cn2 = inb_c ? nb2 : 0.0f;
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
@@ -265,8 +409,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     constexpr float INV_AREA = 1.0f / (float)(K * K);
     __shared__ uint32_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
     __shared__ float lut[256];
+    __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
 
     const int lane = threadIdx.x;
+    window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
@@ -308,20 +454,14 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
 
         for (int r = 0; r < rows; ++r) {
             const int yr = y0 - HALF + r;
-            const bool live = col_in && (unsigned)yr < (unsigned)H;
+            const bool live = col_in & ((unsigned)yr < (unsigned)H);
             const int pix = yr * W + xr;
-            const float rv = live ? ref[pix] : 0.0f;
-            const Vec3 Pw = backproject(a.Kinv, job->Rref, job->tref, xr, yr, depth);
-            unsigned okbits = 0u;
+            const float rvl = ref[live ? pix : 0];
+            const float rv = live ? rvl : 0.0f;
+            JobCP jr = reload(job);
+            const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
             float v[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                bool ok;
-                const void *src = U8 ? (const void *)(a.pairs + job->src_img[s] * a.pair_stride)
-                                     : (const void *)(a.images + job->src_img[s] * a.img_stride);
-                v[s] = project_sample<U8>(a.K, job->Rs[s], job->ts[s], src, lut, sc, Pw, live, ok);
-                okbits |= ok ? (1u << s) : 0u;
-            }
+            const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
 #pragma unroll
             for (int i = 0; i < K - 1; ++i) {
                 ring_r[i] = ring_r[i + 1];
@@ -338,30 +478,17 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
 
             const int yc = yr - HALF;
             const int xc = xr + HALF;
-            const bool outl = lane < OUTW && xc < W;
+            const bool outl = (lane < OUTW) & (xc < W);
             const int pc = yc * W + xc;
             const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
             float m1 = 0.0f, v1 = 0.0f;
             if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
+            float bvs[S], bvvs[S], brvs[S];
+            window_sums<K, S>(ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
             uint32_t votes = 0u;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                float cv = ring_v[s][0];
-                float cvv = ring_v[s][0] * ring_v[s][0];
-                float crv = ring_r[0] * ring_v[s][0];
-#pragma unroll
-                for (int i = 1; i < K; ++i) {
-                    cv = cv + ring_v[s][i];
-                    cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
-                    crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
-                }
-                float bv = cv, bvv = cvv, brv = crv;
-#pragma unroll
-                for (int j = 1; j < K; ++j) {
-                    bv = wave_shl1(bv) + cv;
-                    bvv = wave_shl1(bvv) + cvv;
-                    brv = wave_shl1(brv) + crv;
-                }
+                const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
                 // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
                 const float mean2 = bv * INV_AREA;
                 const float var2 = bvv * INV_AREA - mean2 * mean2;
@@ -424,7 +551,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__res
     for (int i = 0; i < K; ++i) ring[i] = 0.0f;
     for (int r = 0; r < rows; ++r) {
         const int yr = y0 - HALF + r;
-        const bool live = col_in && (unsigned)yr < (unsigned)H;
+        const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const float rv = live ? img[yr * W + xr] : 0.0f;
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) ring[i] = ring[i + 1];
