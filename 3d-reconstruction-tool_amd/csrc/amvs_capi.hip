@@ -52,6 +52,8 @@ struct amvs_ctx {
     int cap_jobs = 0;
     float *d_planes = nullptr;
     int cap_planes = 0;
+    unsigned *d_keys = nullptr;          // plane-sweep running best, [slot][H*W]
+    int cap_keys = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_tile_rows = 0;
@@ -361,6 +363,7 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_aux) (void)hipFree(c->d_aux);
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_planes) (void)hipFree(c->d_planes);
+    if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -558,13 +561,39 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     }
     HIPCHK(c, hipMemcpyAsync(c->d_planes, depths, sizeof(float) * D, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t hw = (size_t)c->H * c->W;
+    if (n_ref > c->cap_keys) {
+        if (c->d_keys) (void)hipFree(c->d_keys);
+        c->d_keys = nullptr; c->cap_keys = 0;
+        HIPCHK(c, hipMalloc(&c->d_keys, sizeof(unsigned) * hw * n_ref));
+        c->cap_keys = n_ref;
+    }
     amvs::SweepArgs a{};
     a.H = c->H; a.W = c->W;
-    a.TH = pick_tile_rows(c, patch_size, n_nbr, n_ref, 0, AMVS_SWEEP_MAX_TH);
-    c->last_tile_rows = a.TH;
+    // tall strips (little halo re-sampling); the planes are chunked so that the launch still has
+    // about four strips per resident wave slot
+    a.TH = AMVS_SWEEP_MAX_TH < c->H ? AMVS_SWEEP_MAX_TH : c->H;
+    if (const char *e = std::getenv("AMVS_SWEEP_TILE_ROWS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= AMVS_SWEEP_MAX_TH) a.TH = v;
+    }
     a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
     a.tiles_y = (c->H + a.TH - 1) / a.TH;
     a.n_jobs = n_ref; a.D = D;
+    {
+        const long long strips = (long long)n_ref * a.tiles_x * a.tiles_y;
+        const long long slots = (long long)c->n_cu * 16;
+        long long want = (4 * slots + strips - 1) / strips;      // chunks for ~4 waves per slot
+        if (want < 1) want = 1;
+        if (want > D) want = D;
+        a.chunk = (int)((D + want - 1) / want);
+        if (const char *e = std::getenv("AMVS_SWEEP_CHUNK")) {
+            const int v = std::atoi(e);
+            if (v >= 1) a.chunk = v < D ? v : D;
+        }
+        a.n_chunks = (D + a.chunk - 1) / a.chunk;
+    }
+    c->last_tile_rows = a.TH;
     a.img_stride = c->stride;
     a.images = c->d_images;
     a.pairs = usable_pairs(c);
@@ -574,12 +603,15 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.depths = c->d_planes;
     a.thresh = thresh;
     a.depth_out = (float *)depth_dev; a.conf_out = (float *)conf_dev;
+    a.keys = c->d_keys;
     a.jobs = c->d_jobs;
     resolve_timing(c);
     c->timing = amvs_timing{};
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_keys, 0, sizeof(unsigned) * hw * n_ref, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, amvs::launch_sweep(patch_size, n_nbr, a, c->stream));
+    HIPCHK(c, amvs::launch_sweep_finish(a, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->timing.sweep_launches = 1;

@@ -44,6 +44,8 @@ struct StepArgs : StepArgsBase {
 
 struct SweepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs, D;
+    int n_chunks, chunk;                     // planes are split into n_chunks groups of `chunk`
+    unsigned *keys;                          // [slot][H*W] running best, merged with atomicMax
     const float *depths;                     // [D] device
     float thresh;
     float *depth_out, *conf_out;             // [slot][H*W]
@@ -55,6 +57,7 @@ int strip_out_width(int K);
 int step_waves_per_cu(int K, int S, bool u8);
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
+hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st);
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
                             int first_img, int n_img, float *mean_out, float *var_out,
                             hipStream_t st);

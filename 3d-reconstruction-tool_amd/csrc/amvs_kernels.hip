@@ -414,12 +414,15 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     const int lane = threadIdx.x;
     window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int cid = t0 % a.n_chunks;          // plane chunk of this wave
+    const int t = t0 / a.n_chunks;
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     const int job_id = t / tiles_per_job;
     const int rem = t - job_id * tiles_per_job;
     const int ty = rem / a.tiles_x;
     const int tx = rem - ty * a.tiles_x;
+    const int d_begin = cid * a.chunk, d_end = min(a.D, d_begin + a.chunk);
 
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
 
     for (int i = 0; i < trows; ++i) best[i][lane] = 0u;
 
-    for (int d = 0; d < a.D; ++d) {
+    for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[d];
         float ring_r[K];
         float ring_v[S][K];
@@ -499,22 +502,30 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             if (outl) {
                 const uint32_t keyv = (votes << 16) | (uint32_t)(65535 - d);
                 const uint32_t cur = best[yc - y0][lane];
-                // plane 0 always enters (torch.max over a volume that starts at 0 votes)
-                if (d == 0 || keyv > cur) best[yc - y0][lane] = keyv;
+                // plane 0 always enters (torch.max over a volume that starts at 0 votes): its key
+                // (0<<16)|65535 beats the initial 0
+                if (keyv > cur) best[yc - y0][lane] = keyv;
             }
         }
     }
 
-    float *__restrict__ depth_out = a.depth_out + job->slot * HW;
-    float *__restrict__ conf_out = a.conf_out + job->slot * HW;
+    unsigned *__restrict__ keys = a.keys + job->slot * HW;
     const int xc = xr + HALF;
-    if (lane < OUTW && xc < W) {
-        for (int i = 0; i < trows; ++i) {
-            const uint32_t b = best[i][lane];
-            const int pc = (y0 + i) * W + xc;
-            depth_out[pc] = a.depths[65535 - (int)(b & 0xFFFFu)];      // :310
-            conf_out[pc] = (float)(b >> 16);
-        }
+    if (lane < OUTW && xc < W)
+        for (int i = 0; i < trows; ++i) atomicMax(&keys[(y0 + i) * W + xc], best[i][lane]);
+}
+
+// decode the merged keys: depth of the winning plane (dense_stereo.py:310) and its vote count
+__global__ __launch_bounds__(256) void plane_sweep_finish_kernel(const unsigned *__restrict__ keys,
+                                                                 const float *__restrict__ depths, long long n,
+                                                                 float *__restrict__ depth_out,
+                                                                 float *__restrict__ conf_out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const unsigned b = keys[i];
+        depth_out[i] = depths[65535 - (int)(b & 0xFFFFu)];
+        conf_out[i] = (float)(b >> 16);
     }
 }
 
@@ -713,13 +724,22 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
 {
-    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
+    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
     switch (K) {
     case 5: AMVS_FOR_S(5, launch_sweep_ks, a, nblk, st)
     case 7: AMVS_FOR_S(7, launch_sweep_ks, a, nblk, st)
     case 11: AMVS_FOR_S(11, launch_sweep_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st)
+{
+    const long long n = (long long)a.n_jobs * a.H * a.W;
+    const int bx = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(plane_sweep_finish_kernel, dim3(bx), dim3(256), 0, st, a.keys, a.depths, n, a.depth_out,
+                       a.conf_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,

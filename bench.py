@@ -4,6 +4,9 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--workload planesweep` benchmarks the sibling path instead (BASELINE config 2: 8 views of
+1280x720, plane-sweep stereo, 64 planes, 5x5 NCC, 6 neighbours; one step = all 8 views).
+
 A "step" is one complete PatchMatch sweep (init, 8 x (2 propagation + 8 refinement) cost
 evaluations, confidence) over this rank's batch of reference views, with every image already
 resident in HBM.  Workload at N=1: BASELINE config 3 -- 16 views of 1920x1080, 7x7 NCC,
@@ -31,9 +34,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(scene_small, patch, srcs, ref, depth_min, depth_max, evals_target_s=15.0):
+def profiled_traffic(kernel_key, workload_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools_profile_summary.py; FETCH_SIZE + WRITE_SIZE in KiB,
+    collected in separate passes, uncorrected -- MI355X_MICROARCH.md notes FETCH_SIZE can
+    under-count wide streaming reads by 2x, dword gathers are uncalibrated).  None if no profile
+    of this exact workload is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(kernel_key)
+        if e and e.get("workload") == workload_key:
+            return int((e["fetch_kib"] + e["write_kib"]) * 1024)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def cpu_baseline(scene_small, patch, srcs, ref, depth_min, depth_max, iters, samples):
     """Time the CPU oracle (oracle/amvs_oracle.c, OpenMP over the host cores) on a bounded
-    sample: one 1080p reference view, 1 iteration x (2 propagation + n refinement) evaluations."""
+    sample: ONE reference view of the workload with the full iteration schedule."""
     from oracle import oracle
     oracle.set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or 16)   # the box's CPU share
     K = scene_small.camera.K.astype(np.float32)
@@ -44,14 +64,13 @@ def cpu_baseline(scene_small, patch, srcs, ref, depth_min, depth_max, evals_targ
     t0 = time.time()
     ctx.patchmatch(0, 0, depth_min, depth_max, 1, ref)            # init + confidence only: warm
     t_fixed = time.time() - t0
-    iters, samples = 2, 8
     t0 = time.time()
     ctx.patchmatch(iters, samples, depth_min, depth_max, 1, ref)
     dt = time.time() - t0 - t_fixed
     n_hyp = H * W * iters * (2 + samples)
     return {"value": n_hyp / max(dt, 1e-9) / 1e6, "unit": "Mpx-hyp/s", "cores": oracle.num_threads(),
             "kind": "port",
-            "sample": f"1 of the 16 views at {W}x{H}, {iters} iterations x (2+{samples}) evaluations = "
+            "sample": f"1 of the views at {W}x{H}, {iters} iterations x (2+{samples}) evaluations = "
                       f"{n_hyp/1e6:.1f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, OpenMP)"}
 
 
@@ -68,7 +87,11 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["patchmatch", "planesweep"], default="patchmatch")
+    ap.add_argument("--planes", type=int, default=64)
     args = ap.parse_args()
+    if args.workload == "planesweep":
+        return main_planesweep(args)
 
     import torch
     import torch.distributed as dist
@@ -182,20 +205,125 @@ def main():
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": profiled_traffic(f"pm_step_kernel<{args.patch},{S}>",
+                                                     f"{vpg}x{W}x{H}"),
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
             "confidence_ms_per_step": round(conf_ms / args.steps, 3),
         }
+        # "dense points/s": fuse + filter the maps of the last step on the host (untimed above;
+        # reference mvs_patchmatch.py:536-588) and relate the cloud to sweep + fusion time
+        if world == 1:
+            t_f = time.perf_counter()
+            pmh = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+            pmh.K_scaled, pmh.min_views = sc.camera.K.copy(), 3
+            dn, cf = depth.cpu().numpy(), conf.cpu().numpy()
+            maps = {r: amvs.DepthNormalMap(depth=dn[i], normal=None, confidence=cf[i]) for i, r in enumerate(refs)}
+            proc = {r: {"color": sc.colors[r]} for r in refs}
+            pts, cols = pmh._fuse_depth_maps(maps, proc, sc.poses)
+            raw = len(pts)
+            if raw:
+                pts, cols = pmh._filter_points(pts, cols)
+            t_f = time.perf_counter() - t_f
+            out["dense_points"] = {"raw": raw, "final": int(len(pts)),
+                                   "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),
+                                   "host_fusion_s": round(t_f, 3)}
         if world == 1 and not args.no_cpu_baseline:
             ref = n_views // 2
-            out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources[ref], ref, sc.depth_min, sc.depth_max)
+            out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources[ref], ref, sc.depth_min, sc.depth_max,
+                                               args.iters, args.samples)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
 
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_planesweep(args):
+    """BASELINE config 2: plane-sweep stereo (dense_stereo.py:222-316) over all views of a
+    1280x720 8-view scene, 64 inverse-depth planes, 5x5 NCC, 6 nearest neighbours."""
+    import torch
+
+    import amvs
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    H, W = (720, 1280) if (args.height, args.width) == (1080, 1920) else (args.height, args.width)
+    n_views = 8 if args.views_per_gpu == 16 else args.views_per_gpu
+    patch = 5 if args.patch == 7 else args.patch
+    S, D = 6, args.planes
+    sc = make_scene(n_views, H, W, seed=1234, device=str(dev))
+    ds = amvs.DenseStereoReconstructor.__new__(amvs.DenseStereoReconstructor)
+    ids = sorted(sc.poses)
+    nbrs = {r: ds._find_neighbors(r, ids, sc.poses, k=S) for r in ids}
+    depths = (1.0 / np.linspace(1 / sc.depth_max, 1 / sc.depth_min, D)).astype(np.float32)
+    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=0)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
+    lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(dev)
+    for i in ids:
+        codes = torch.round(torch.from_numpy(sc.grays[i]).to(dev) * 255.0).clamp(0, 255).long()
+        g = lut[codes].contiguous()
+        sc.grays[i] = g.cpu().numpy()
+        eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
+        torch.cuda.synchronize()
+    dmap = torch.empty((n_views, H, W), dtype=torch.float32, device=dev)
+    conf = torch.empty((n_views, H, W), dtype=torch.float32, device=dev)
+    refs = ids
+    nb = [nbrs[r] for r in refs]
+
+    def step():
+        eng.plane_sweep_device(refs, nb, depths, patch, 0.8, dmap.data_ptr(), conf.data_ptr())
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        step()
+        kernel_ms += eng.timing()["sweep_ms"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_hyp = n_views * H * W * D
+    value = n_hyp * args.steps / elapsed / 1e6
+    bytes_per_hyp = 4 * S + 4 + 8.0 / D                  # SURVEY.md section 8(d)
+    launch_ms = kernel_ms / args.steps
+    achieved = bytes_per_hyp * n_hyp / (launch_ms * 1e-3) / 1e9
+    out = {"metric": "Mpixel-hypotheses/s (plane sweep)", "value": round(value, 1), "unit": "Mpx-hyp/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 2: {n_views}-view {W}x{H} plane-sweep stereo, {D} planes, "
+                                  f"{patch}x{patch} NCC, {S} neighbours", "sampling": eng.sampling_mode(),
+                      "tile_rows": eng.last_tile_rows(), "pixel_hypotheses_per_step": n_hyp},
+           "roofline": {"bound": "hbm", "kernel": f"plane_sweep_kernel<{patch},{S}>", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": profiled_traffic(f"plane_sweep_kernel<{patch},{S}>", f"{n_views}x{W}x{H}"),
+                        "algorithmic_bytes_per_launch": int(bytes_per_hyp * n_hyp),
+                        "avg_launch_ms": round(launch_ms, 4), "launches_timed": args.steps}}
+    if not args.no_cpu_baseline:
+        oracle.set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or 16)
+        r = n_views // 2
+        ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), sc.grays[r], sc.poses[r].R, sc.poses[r].t,
+                                 [sc.grays[i] for i in nbrs[r]], [sc.poses[i].R for i in nbrs[r]],
+                                 [sc.poses[i].t for i in nbrs[r]], patch)
+        reps = 8
+        t0 = time.time()
+        for _ in range(reps):
+            ctx.plane_sweep(depths, 0.8)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(reps * H * W * D / dt / 1e6, 2), "unit": "Mpx-hyp/s",
+                               "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"1 view at {W}x{H}, all {D} planes, {reps} repetitions = "
+                                         f"{reps*H*W*D/1e6:.0f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, OpenMP)"}
+    print(json.dumps(out), flush=True)
+    eng.close()
 
 
 if __name__ == "__main__":
