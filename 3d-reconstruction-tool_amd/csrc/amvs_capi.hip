@@ -741,6 +741,24 @@ int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float
     return AMVS_OK;
 }
 
+int amvs_selftest_lean_math(amvs_ctx *c, uint64_t mismatches[2])
+{
+    if (!c || !mismatches) return AMVS_EINVAL;
+    int rc = bind_device(c);
+    if (rc) return rc;
+    unsigned long long *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, 16));
+    hipError_t e = hipMemsetAsync(d, 0, 16, c->stream);
+    if (e == hipSuccess) e = amvs::launch_lean_math_check(d, c->stream);
+    unsigned long long h[2] = {~0ull, ~0ull};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("selftest: ") + hipGetErrorString(e));
+    mismatches[0] = h[0]; mismatches[1] = h[1];
+    return AMVS_OK;
+}
+
 int amvs_rng_fill(amvs_ctx *c, uint64_t seed, uint32_t stream_view, uint32_t draw, int64_t n, float *u_out,
                   float *n_out)
 {

@@ -12,6 +12,42 @@
 
 namespace amvs {
 
+// Correctly rounded reciprocal and square root without the compiler's IEEE expansions (which
+// cost ~17 and ~22 plain VALU issue slots on gfx950, tools/shift_rate.hip).  For every float
+// whose biased exponent lies in [32, 222] (2^-95 <= |x| < 2^96)
+//     v_rcp_f32 + one FMA correction        == 1.0f / x        (both signs, 3.2e9 inputs)
+//     v_rsq_f32 + Goldschmidt + FMA residual == sqrtf(x)        (x > 0, 1.6e9 inputs; NaN for x < 0)
+// bit for bit -- verified EXHAUSTIVELY on MI355X (tools/lean_math.hip, tests/test_hip_parity.py::
+// test_lean_math_exhaustive).  Outside that range (zero, denormals, huge, negative for sqrt,
+// NaN/inf) the IEEE expansion runs, behind a wave-uniform branch that is almost never taken.
+AMVS_DEV float rcp_rn(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(r, e, r);
+    const bool ok = (((__float_as_uint(x) >> 23) & 0xFFu) - 32u) <= 190u;
+    if (__builtin_expect(!__all(ok), 0)) r = ok ? r : 1.0f / x;
+    return r;
+}
+
+AMVS_DEV float sqrt_rn(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    // +-0 (all-zero sample windows are common near image borders) is returned as is; a negative
+    // in-range argument already produced NaN through v_rsq_f32, as sqrtf does
+    g = x == 0.0f ? x : g;
+    const bool ok = ((((__float_as_uint(x) >> 23) & 0xFFu) - 32u) <= 190u) | (x == 0.0f);
+    if (__builtin_expect(!__all(ok), 0)) g = ok ? g : __builtin_sqrtf(x);
+    return g;
+}
+
 // ---------------------------------------------------------------- RNG ------
 // Counter-hash generator standing in for torch.rand / torch.randn
 // (mvs_patchmatch.py:271,279,280,471,475).  A "draw" gives every pixel one
@@ -90,7 +126,7 @@ AMVS_DEV void normal_pair(uint32_t w, float &n0, float &n1)
     uint32_t a = w >> 16, b = w & 0xFFFFu;
     float t = (float)a + 0.5f;
     float lnu = log_poly(t) + (-11.090354888959125f);
-    float r = __builtin_sqrtf(-2.0f * lnu);
+    float r = sqrt_rn(-2.0f * lnu);
     uint32_t q = b >> 14;
     float th = ((float)(b & 0x3FFFu) * 0x1p-14f) * 1.57079632679489662f;
     float s, c;
@@ -142,9 +178,9 @@ AMVS_DEV float qdiv(float a, float b, float rb)
 // F.normalize(v, dim=-1) = v / max(||v||, 1e-12)   (mvs_patchmatch.py:281,476)
 AMVS_DEV void normalize3(float &x, float &y, float &z)
 {
-    float n = __builtin_sqrtf(x * x + y * y + z * z);
+    float n = sqrt_rn(x * x + y * y + z * z);
     float d = n > 1e-12f ? n : 1e-12f;
-    float rd = 1.0f / d;
+    float rd = rcp_rn(d);
     x = qdiv(x, d, rd); y = qdiv(y, d, rd); z = qdiv(z, d, rd);
 }
 
@@ -233,7 +269,7 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
     float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
     float zz = z + 1e-8f;
-    float rz = 1.0f / zz;
+    float rz = rcp_rn(zz);
     float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];

@@ -66,6 +66,7 @@ hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, in
 hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,
                        float log_scale, float log_min, float *depth, float *normal, float *cost,
                        hipStream_t st);
+hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st);
 hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw, long long n,
                            float *u_out, float *n_out, hipStream_t st);
 

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
             const float mean2 = bv * INV_AREA;
             const float var2 = bvv * INV_AREA - mean2 * mean2;
             const float cov = brv * INV_AREA - m1 * mean2;
-            const float ncc = cov / (__builtin_sqrtf(v1 * var2) + 1e-8f);
+            const float den = sqrt_rn(v1 * var2) + 1e-8f;
+            const float ncc = qdiv(cov, den, rcp_rn(den));
             const float cost = 1.0f - ncc;
             const bool oks = (okc >> s) & 1u;
             // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         if (mode == MODE_CONF) { aux[pc] = cnt; continue; }
 
         // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
-        const float avg = total / (cnt + 1e-8f);
+        const float cden = cnt + 1e-8f;
+        const float avg = qdiv(total, cden, rcp_rn(cden));
         const float newc = cnt >= 2.0f ? avg : __builtin_inff();
         if (mode == MODE_EVAL) { aux[pc] = newc; continue; }
 
@@ -496,7 +498,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
                 const float mean2 = bv * INV_AREA;
                 const float var2 = bvv * INV_AREA - mean2 * mean2;
                 const float cov = brv * INV_AREA - m1 * mean2;
-                const float ncc = cov / __builtin_sqrtf(v1 * var2 + 1e-8f);
+                const float den = sqrt_rn(v1 * var2 + 1e-8f);
+                const float ncc = qdiv(cov, den, rcp_rn(den));
                 if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
             }
             if (outl) {
@@ -656,6 +659,30 @@ __global__ __launch_bounds__(256) void rng_fill_kernel(unsigned long long seed, 
             n_out[3 * i] = g0; n_out[3 * i + 1] = g1; n_out[3 * i + 2] = g2;
         }
     }
+}
+
+// ------------------------------------------------------------------ self test ----
+// Compare rcp_rn / sqrt_rn with the IEEE expansions on EVERY float bit pattern.
+__global__ __launch_bounds__(256) void lean_math_check_kernel(unsigned long long *mismatch)
+{
+    unsigned long long bad_rcp = 0, bad_sqrt = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32);
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = rcp_rn(x), b = 1.0f / x;
+        const float c = sqrt_rn(x), d = __builtin_sqrtf(x);
+        // NaN results compare equal when both are NaN
+        bad_rcp += (__float_as_uint(a) != __float_as_uint(b)) & !((a != a) & (b != b));
+        bad_sqrt += (__float_as_uint(c) != __float_as_uint(d)) & !((c != c) & (d != d));
+    }
+    if (bad_rcp) atomicAdd(&mismatch[0], bad_rcp);
+    if (bad_sqrt) atomicAdd(&mismatch[1], bad_sqrt);
+}
+
+hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st)
+{
+    hipLaunchKernelGGL(lean_math_check_kernel, dim3(8192), dim3(256), 0, st, mismatch);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ dispatch -----

@@ -197,6 +197,12 @@ class Engine:
         self._chk(self._lib.amvs_box_stats(self._h, int(view), int(patch_size), _p(m), _p(v)))
         return m, v
 
+    def selftest_lean_math(self):
+        """(reciprocal mismatches, sqrt mismatches) against IEEE over all 2^32 float patterns."""
+        out = (C.c_uint64 * 2)()
+        self._chk(self._lib.amvs_selftest_lean_math(self._h, out))
+        return int(out[0]), int(out[1])
+
     def rng_fill(self, seed, stream_view, draw, n):
         u = np.empty(n, np.float32)
         nz = np.empty((n, 3), np.float32)

@@ -140,6 +140,12 @@ int amvs_box_stats(amvs_ctx *ctx, int view, int patch_size, float *mean_out, flo
 int amvs_rng_fill(amvs_ctx *ctx, uint64_t seed, uint32_t stream_view, uint32_t draw,
                   int64_t n, float *u_out, float *n_out);
 
+/* Self test: the kernels replace the IEEE divide / sqrt expansions by v_rcp_f32 / v_rsq_f32 with
+ * FMA corrections (plus an IEEE path for out-of-range operands).  Compares both against
+ * 1.0f/x and sqrtf(x) on ALL 2^32 float bit patterns; mismatches[0] = reciprocal,
+ * mismatches[1] = square root (both must be 0 for bit-exact parity with the CPU oracle).      */
+int amvs_selftest_lean_math(amvs_ctx *ctx, uint64_t mismatches[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -350,11 +350,14 @@ static void ncc_map(const float *img1, const float *mean1, const float *var1,
         float mean2 = b_v[i] * inv;
         float var2 = b_vv[i] * inv - mean2 * mean2;
         float cov = b_rv[i] * inv - mean1[i] * mean2;
+        /* quotients are formed as qdiv(a, b, RN(1/b)) (see qdiv above) */
         if (variant == 0) {
-            float ncc = cov / (sqrtf(var1[i] * var2) + 1e-8f);
+            float den = sqrtf(var1[i] * var2) + 1e-8f;
+            float ncc = qdiv(cov, den, 1.0f / den);
             out[i] = 1.0f - ncc;
         } else {
-            out[i] = cov / sqrtf(var1[i] * var2 + 1e-8f);
+            float den = sqrtf(var1[i] * var2 + 1e-8f);
+            out[i] = qdiv(cov, den, 1.0f / den);
         }
     }
 }
@@ -453,7 +456,8 @@ ORC_API void orc_patch_cost(orc_ctx_t *c, const float *depth, float *cost_out)
             if (c->valid[i]) { c->total[i] = c->total[i] + c->cost_s[i]; c->count[i] += 1.0f; }
     }
     for (size_t i = 0; i < n; ++i) {
-        float avg = c->total[i] / (c->count[i] + 1e-8f);
+        float cden = c->count[i] + 1e-8f;
+        float avg = qdiv(c->total[i], cden, 1.0f / cden);
         cost_out[i] = (c->count[i] >= 2.0f) ? avg : INFINITY;
     }
 }

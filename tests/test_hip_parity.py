@@ -42,6 +42,15 @@ def _eq(a, b, what):
 
 
 # ------------------------------------------------------------------ primitives ----
+def test_lean_math_exhaustive(eng_a):
+    """rcp_rn / sqrt_rn (v_rcp / v_rsq + FMA corrections, IEEE path out of range) equal 1.0f/x and
+    sqrtf(x) on every one of the 2^32 float bit patterns: the replacement of the IEEE expansions
+    cannot change a single bit anywhere."""
+    bad_rcp, bad_sqrt = eng_a.selftest_lean_math()
+    assert (bad_rcp, bad_sqrt) == (0, 0)
+
+
+
 def test_rng_bit_exact(eng_a):
     from oracle import oracle
     for seed, view, draw, n in ((42, 0, 0, 5000), (2**40 + 17, 3, 9, 12345), (0, 31, 64, 777)):
