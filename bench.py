@@ -99,10 +99,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # AMVS_BENCH_BACKEND=gloo + AMVS_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank path on a
+    # single-GPU box (all ranks on cuda:0, all-gather staged through the host); never set by the
+    # driver -- the real run is one rank per GPU over RCCL
+    backend = os.environ.get("AMVS_BENCH_BACKEND", "nccl")
+    if os.environ.get("AMVS_BENCH_ONE_DEVICE") == "1":
+        local = 0
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -146,8 +155,13 @@ def main():
             with torch.cuda.stream(stream):
                 packed = torch.cat([depth.reshape(n_loc, -1), normal.reshape(n_loc, -1),
                                     conf.reshape(n_loc, -1)], dim=1)
-                allgather_packed(packed, n_views, 5 * H * W)
+                if backend != "nccl":
+                    stream.synchronize()
+                    packed = packed.cpu()
+                gathered[0] = allgather_packed(packed, n_views, 5 * H * W)
         eng.sync()
+
+    gathered = [None]
 
     def fence():
         torch.cuda.synchronize()
@@ -170,9 +184,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # every rank must now hold every view's maps: its own block is checked bit for bit
+        g = gathered[0]
+        assert g is not None and tuple(g.shape) == (n_views, 5 * H * W)
+        mine_rows = g[mine[0]: mine[0] + n_loc].to(dev)
+        assert torch.equal(mine_rows[:, : H * W], depth.reshape(n_loc, -1)), "all-gather: own depth block differs"
+        assert torch.equal(mine_rows[:, 4 * H * W:], conf.reshape(n_loc, -1)), "all-gather: own confidence block differs"
 
     n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
