@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
-SUPPORTED_PATCH_SIZES = (5, 7, 11)
+SUPPORTED_PATCH_SIZES = (3, 5, 7, 9, 11)
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int)

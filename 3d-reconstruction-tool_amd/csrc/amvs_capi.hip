@@ -88,7 +88,7 @@ int check_patch_src(amvs_ctx *c, int patch, int n_src)
 {
     if (!amvs::patch_supported(patch))
         return fail(c, AMVS_EUNSUPPORTED,
-                    "patch_size " + std::to_string(patch) + " not compiled in (supported: 5, 7, 11)");
+                    "patch_size " + std::to_string(patch) + " not compiled in (supported: 3, 5, 7, 9, 11)");
     if (n_src < 2 || n_src > AMVS_MAX_SRC)
         return fail(c, AMVS_EUNSUPPORTED,
                     "n_src " + std::to_string(n_src) + " outside [2, " + std::to_string(AMVS_MAX_SRC) + "]");

@@ -728,22 +728,26 @@ static int step_occupancy_ks(bool u8)
 int step_waves_per_cu(int K, int S, bool u8)
 {
     switch (K) {
+    case 3: AMVS_FOR_S(3, step_occupancy_ks, u8)
     case 5: AMVS_FOR_S(5, step_occupancy_ks, u8)
     case 7: AMVS_FOR_S(7, step_occupancy_ks, u8)
+    case 9: AMVS_FOR_S(9, step_occupancy_ks, u8)
     case 11: AMVS_FOR_S(11, step_occupancy_ks, u8)
     default: return 8;
     }
 }
 
-bool patch_supported(int K) { return K == 5 || K == 7 || K == 11; }
+bool patch_supported(int K) { return K == 3 || K == 5 || K == 7 || K == 9 || K == 11; }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 {
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
     switch (K) {
+    case 3: AMVS_FOR_S(3, launch_step_ks, a, nblk, st)
     case 5: AMVS_FOR_S(5, launch_step_ks, a, nblk, st)
     case 7: AMVS_FOR_S(7, launch_step_ks, a, nblk, st)
+    case 9: AMVS_FOR_S(9, launch_step_ks, a, nblk, st)
     case 11: AMVS_FOR_S(11, launch_step_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
@@ -753,8 +757,10 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
 {
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
     switch (K) {
+    case 3: AMVS_FOR_S(3, launch_sweep_ks, a, nblk, st)
     case 5: AMVS_FOR_S(5, launch_sweep_ks, a, nblk, st)
     case 7: AMVS_FOR_S(7, launch_sweep_ks, a, nblk, st)
+    case 9: AMVS_FOR_S(9, launch_sweep_ks, a, nblk, st)
     case 11: AMVS_FOR_S(11, launch_sweep_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
@@ -778,6 +784,14 @@ hipError_t launch_box_stats(int K, const float *images, long long img_stride, in
     const int tiles_y = (H + TH - 1) / TH;
     const dim3 grid(n_img * tiles_x * tiles_y), blk(AMVS_WAVE);
     switch (K) {
+    case 3:
+        hipLaunchKernelGGL((box_stats_kernel<3>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 9:
+        hipLaunchKernelGGL((box_stats_kernel<9>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
     case 5:
         hipLaunchKernelGGL((box_stats_kernel<5>), grid, blk, 0, st, images, img_stride, H, W, TH,
                            tiles_x, tiles_y, first_img, mean_out, var_out);

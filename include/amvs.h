@@ -41,7 +41,7 @@ typedef struct amvs_ctx amvs_ctx;
  * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
  * and (float)ln dmin formed in double by the host, as :268-271 does.           */
 typedef struct {
-    int32_t patch_size;       /* odd; compiled: 5, 7, 11                          */
+    int32_t patch_size;       /* odd; compiled: 3, 5, 7, 9, 11                         */
     int32_t num_iterations;
     int32_t num_samples;
     int32_t tile_rows;        /* rows per wave strip; 0 = choose automatically    */

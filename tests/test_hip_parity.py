@@ -72,7 +72,7 @@ def test_init_state_bit_exact(eng_a, scene_a):
     _eq(c, oc, "init cost")
 
 
-@pytest.mark.parametrize("k", [5, 7, 11])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
 def test_box_stats_bit_exact(eng_a, scene_a, k):
     from oracle import oracle
     for v in (0, 3):
@@ -91,7 +91,7 @@ def _mixed_depth(scene, ref, seed):
     return d
 
 
-@pytest.mark.parametrize("k", [5, 7, 11])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
 @pytest.mark.parametrize("srcs", [[1, 3, 0, 4], [3, 1], [0, 1, 4], [1, 3, 0, 4, 2][:4]])
 def test_eval_cost_bit_exact(eng_a, scene_a, k, srcs):
     ref = 2
@@ -217,7 +217,7 @@ def test_ragged_shapes_bit_exact(amvs_mod, shape):
     with amvs_mod.Engine(H, W, 4, K) as eng:
         for i in range(4):
             eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
-        for k in (5, 11):
+        for k in (3, 5, 9, 11):
             p = make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max)
             depth, normal, conf = eng.patchmatch([1], [[0, 2, 3]], p, 9)
             ctx = oracle.ViewContext(K, sc.grays[1], sc.poses[1].R, sc.poses[1].t,
@@ -305,7 +305,9 @@ def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
     d = scene_a.gt_depth[2]
     with pytest.raises(AmvsError, match="patch_size"):
-        eng_a.eval_cost(2, [1, 3], 9, d)
+        eng_a.eval_cost(2, [1, 3], 13, d)
+    with pytest.raises(AmvsError, match="patch_size"):
+        eng_a.eval_cost(2, [1, 3], 6, d)
     with pytest.raises(AmvsError, match="n_src"):
         eng_a.eval_cost(2, [1], 7, d)
     with pytest.raises(AmvsError, match="not uploaded"):
