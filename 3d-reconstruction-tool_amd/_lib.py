@@ -61,6 +61,10 @@ SIGNATURES = {
     "amvs_init_state": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_float,
                                   f32p, f32p, f32p]),
     "amvs_box_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_fuse_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint8),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_float, C.c_int,
+                                   C.POINTER(C.c_int64)]),
+    "amvs_fetch_cloud": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
     "amvs_selftest_lean_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "amvs_rng_fill": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, f32p, f32p]),
 }

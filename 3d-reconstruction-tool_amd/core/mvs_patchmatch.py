@@ -43,7 +43,7 @@ class PatchMatchMVS:
                  num_iterations: int = 3, num_samples: int = 8, min_views: int = 3,
                  depth_min: float = 0.1, depth_max: float = 100.0, *,
                  seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
-                 process_group=None):
+                 process_group=None, device_fusion: bool = True):
         self.camera = camera
         self.scale = scale
         self.patch_size = patch_size
@@ -55,6 +55,7 @@ class PatchMatchMVS:
         self.seed = seed
         self.views_per_batch = max(1, int(views_per_batch))
         self.process_group = process_group
+        self.device_fusion = device_fusion
         self.device_id = _parallel.local_device() if device is None else int(device)
         print(f"PatchMatch MVS using GPU: HIP device {self.device_id} (gfx950 kernels)")
         # scaled intrinsics: first two rows times `scale` (reference :69-70)
@@ -96,11 +97,17 @@ class PatchMatchMVS:
         depth_maps = self._sweep(jobs, proc_images, poses, cam_indices)
 
         print("\nFusing depth maps...")
-        points, colors = self._fuse_depth_maps(depth_maps, proc_images, poses)
-        print(f"  Raw points: {len(points):,}")
-        if len(points) > 0:
-            points, colors = self._filter_points(points, colors)
-            print(f"  After filtering: {len(points):,}")
+        if self.device_fusion and self._engine is not None and depth_maps:
+            points, colors, raw = self._fuse_filter_device(depth_maps, proc_images, poses)
+            print(f"  Raw points: {raw:,}")
+            if raw > 0:
+                print(f"  After filtering: {len(points):,}")
+        else:
+            points, colors = self._fuse_depth_maps(depth_maps, proc_images, poses)
+            print(f"  Raw points: {len(points):,}")
+            if len(points) > 0:
+                points, colors = self._filter_points(points, colors)
+                print(f"  After filtering: {len(points):,}")
         print(f"\nPatchMatch MVS completed in {time.time() - t0:.1f}s")
         return points, colors
 
@@ -218,6 +225,21 @@ class PatchMatchMVS:
         return {jobs[j][0]: local[j] for j in sorted(local)}
 
     # ------------------------------------------------------------ fusion / filter --
+    def _fuse_filter_device(self, depth_maps: Dict[int, "DepthNormalMap"], images: Dict,
+                            poses: Dict[int, CameraPose]):
+        """_fuse_depth_maps + _filter_points on the GPU (amvs_fuse_filter): float64, same order,
+        bit-identical clouds; returns (points, colors, raw point count)."""
+        ids = [idx for idx, dm in depth_maps.items() if np.any(dm.confidence >= self.min_views)]
+        if not ids:
+            return np.array([]).reshape(0, 3), np.array([]).reshape(0, 3), 0
+        depth = np.stack([depth_maps[i].depth for i in ids])
+        conf = np.stack([depth_maps[i].confidence for i in ids])
+        cols = np.stack([images[i]["color"] for i in ids])
+        K_inv = np.linalg.inv(self.K_scaled)
+        return self._engine.fuse_filter(depth, conf, cols, K_inv, [(poses[i].R, poses[i].t) for i in ids],
+                                        self.min_views, do_filter=True)
+
+
     def _fuse_depth_maps(self, depth_maps: Dict[int, DepthNormalMap], images: Dict,
                          poses: Dict[int, CameraPose]) -> Tuple[np.ndarray, np.ndarray]:
         """Back-project pixels with confidence >= min_views to world space (reference :536-570)."""

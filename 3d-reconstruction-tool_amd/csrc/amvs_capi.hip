@@ -54,6 +54,9 @@ struct amvs_ctx {
     int cap_planes = 0;
     unsigned *d_keys = nullptr;          // plane-sweep running best, [slot][H*W]
     int cap_keys = 0;
+    double *d_cloud_pts = nullptr;       // result of the last amvs_fuse_filter
+    unsigned char *d_cloud_rgb = nullptr;
+    long long cloud_n = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_tile_rows = 0;
@@ -364,6 +367,8 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -737,6 +742,60 @@ int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float
     const size_t hw = (size_t)c->H * c->W;
     HIPCHK(c, hipMemcpyAsync(mean_out, s.mean + view * c->stride, 4 * hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(var_out, s.var + view * c->stride, 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+int amvs_fuse_filter(amvs_ctx *c, int n_maps, const void *depth, const void *conf, int maps_on_device,
+                     const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
+                     float min_views, int do_filter, int64_t counts[2])
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_maps < 1 || !depth || !conf || !colors_bgr_host || !K_inv || !poses || !counts)
+        return fail(c, AMVS_EINVAL, "bad argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W, n = hw * (size_t)n_maps;
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    c->d_cloud_pts = nullptr; c->d_cloud_rgb = nullptr; c->cloud_n = 0;
+    float *dd = nullptr, *dc = nullptr;
+    unsigned char *dbgr = nullptr;
+    auto cleanup = [&]() {
+        if (!maps_on_device) { if (dd) (void)hipFree(dd); if (dc) (void)hipFree(dc); }
+        if (dbgr) (void)hipFree(dbgr);
+    };
+    hipError_t e = hipMalloc(&dbgr, 3 * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbgr, colors_bgr_host, 3 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && !maps_on_device) {
+        e = hipMalloc(&dd, 4 * n);
+        if (e == hipSuccess) e = hipMalloc(&dc, 4 * n);
+        if (e == hipSuccess) e = hipMemcpyAsync(dd, depth, 4 * n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc, conf, 4 * n, hipMemcpyHostToDevice, c->stream);
+    } else if (e == hipSuccess) {
+        dd = (float *)depth; dc = (float *)conf;
+    }
+    long long cnt[2] = {0, 0};
+    if (e == hipSuccess)
+        e = amvs::fuse_filter(dd, dc, dbgr, n_maps, c->H, c->W, K_inv, poses, min_views, do_filter != 0,
+                              &c->d_cloud_pts, &c->d_cloud_rgb, cnt, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("fuse_filter: ") + hipGetErrorString(e));
+    counts[0] = cnt[0]; counts[1] = cnt[1];
+    c->cloud_n = cnt[1];
+    return AMVS_OK;
+}
+
+int amvs_fetch_cloud(amvs_ctx *c, double *points, uint8_t *colors)
+{
+    if (!c) return AMVS_EINVAL;
+    if (c->cloud_n == 0) return AMVS_OK;
+    if (!points || !colors) return fail(c, AMVS_EINVAL, "NULL output");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(points, c->d_cloud_pts, sizeof(double) * 3 * c->cloud_n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(colors, c->d_cloud_rgb, 3 * c->cloud_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMVS_OK;
 }

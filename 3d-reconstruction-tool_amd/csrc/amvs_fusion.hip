@@ -1,0 +1,299 @@
+// amvs_fusion.hip -- device-side fusion and filtering of the per-view maps into a point cloud
+// (reference: PatchMatchMVS._fuse_depth_maps mvs_patchmatch.py:536-570 and _filter_points
+// :572-588, both float64 NumPy on the host there).  Same results bit for bit: float64 throughout,
+// 3-term products as the left-to-right FMA chain NumPy's matmul uses, order-preserving stream
+// compaction (np.where order), np.median / np.percentile(95, linear) on device-sorted columns,
+// voxel de-duplication as a stable radix sort of the int64 keys keeping the first point of every
+// run (np.unique(return_index=True)).  hipCUB supplies the scans / sorts / selects.
+#include "amvs_kernels.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace amvs {
+
+namespace {
+
+#define FCHK(call)                                 \
+    do {                                           \
+        hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) return e_;           \
+    } while (0)
+
+// per-pixel flag: confidence >= min_views (mvs_patchmatch.py:545)
+__global__ __launch_bounds__(256) void fuse_flag_kernel(const float *__restrict__ conf, long long n,
+                                                        float min_views, unsigned char *__restrict__ flag)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        flag[i] = conf[i] >= min_views ? 1 : 0;
+}
+
+// back-project the selected pixels: rays = [x,y,1] @ K_inv.T; X = rays*d; Xw = (X - t) @ R
+// (mvs_patchmatch.py:556-562), all float64
+__global__ __launch_bounds__(256) void fuse_project_kernel(const long long *__restrict__ sel, long long m,
+                                                           const float *__restrict__ depth,
+                                                           const unsigned char *__restrict__ bgr, int H, int W,
+                                                           const double *__restrict__ Kinv,
+                                                           const double *__restrict__ poses,   // [n_maps][12]: R row-major, t
+                                                           double *__restrict__ pts, unsigned char *__restrict__ rgb)
+{
+    const long long HW = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long g = sel[i];
+        const int map = (int)(g / HW);
+        const long long p = g - map * HW;
+        const double y = (double)(p / W), x = (double)(p % W);
+        const double d = (double)depth[g];
+        const double *R = poses + 12 * map, *t = R + 9;
+        double c[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ray = fma(1.0, Kinv[3 * j + 2], fma(y, Kinv[3 * j + 1], x * Kinv[3 * j]));
+            c[j] = ray * d - t[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pts[3 * i + j] = fma(c[2], R[6 + j], fma(c[1], R[3 + j], c[0] * R[j]));
+        rgb[3 * i] = bgr[3 * g + 2]; rgb[3 * i + 1] = bgr[3 * g + 1]; rgb[3 * i + 2] = bgr[3 * g];   // BGR -> RGB (:565)
+    }
+}
+
+__global__ __launch_bounds__(256) void column_kernel(const double *__restrict__ pts, long long m, int col,
+                                                     double *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = pts[3 * i + col];
+}
+
+// np.linalg.norm(points - centroid, axis=1): sqrt((dx*dx + dy*dy) + dz*dz)
+__global__ __launch_bounds__(256) void dist_kernel(const double *__restrict__ pts, long long m, double cx, double cy,
+                                                   double cz, double *__restrict__ dist)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x) {
+        const double dx = pts[3 * i] - cx, dy = pts[3 * i + 1] - cy, dz = pts[3 * i + 2] - cz;
+        dist[i] = sqrt(dx * dx + dy * dy + dz * dz);
+    }
+}
+
+__global__ __launch_bounds__(256) void below_kernel(const double *__restrict__ dist, long long m, double thr,
+                                                    unsigned char *__restrict__ flag)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x)
+        flag[i] = dist[i] < thr ? 1 : 0;
+}
+
+// voxel key of mvs_patchmatch.py:583-586 for the points selected by `sel`
+__global__ __launch_bounds__(256) void voxel_key_kernel(const double *__restrict__ pts, const long long *__restrict__ sel,
+                                                        long long m, double voxel, long long *__restrict__ keys)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long s = sel[i];
+        const long long ix = (long long)floor(pts[3 * s] / voxel);
+        const long long iy = (long long)floor(pts[3 * s + 1] / voxel);
+        const long long iz = (long long)floor(pts[3 * s + 2] / voxel);
+        keys[i] = ix * 1000000000ll + iy * 1000000ll + iz;
+    }
+}
+
+__global__ __launch_bounds__(256) void run_head_kernel(const long long *__restrict__ keys, long long m,
+                                                       unsigned char *__restrict__ flag)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x)
+        flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(long long *__restrict__ out, long long m)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = i;
+}
+
+// out[i] = src[map[idx[i]]] for points and colours
+__global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ pts, const unsigned char *__restrict__ rgb,
+                                                     const long long *__restrict__ sel, const long long *__restrict__ pick,
+                                                     long long m, double *__restrict__ pts_out,
+                                                     unsigned char *__restrict__ rgb_out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long s = sel[pick[i]];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pts_out[3 * i + j] = pts[3 * s + j]; rgb_out[3 * i + j] = rgb[3 * s + j]; }
+    }
+}
+
+inline dim3 grid_for(long long n) { long long b = (n + 255) / 256; return dim3((unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b))); }
+
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+
+// order-preserving selection of the indices [0,n) whose flag is set
+hipError_t select_indices(const unsigned char *flag, long long n, long long *out, long long *d_count,
+                          long long *h_count, Scratch &tmp, hipStream_t st)
+{
+    hipcub::CountingInputIterator<long long> iota(0);
+    size_t bytes = 0;
+    FCHK(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota, flag, out, d_count, (int)n, st));
+    FCHK(tmp.need(bytes));
+    FCHK(hipcub::DeviceSelect::Flagged(tmp.p, bytes, iota, flag, out, d_count, (int)n, st));
+    FCHK(hipMemcpyAsync(h_count, d_count, sizeof(long long), hipMemcpyDeviceToHost, st));
+    return hipStreamSynchronize(st);
+}
+
+hipError_t sort_keys(double *in, double *out, long long n, Scratch &tmp, hipStream_t st)
+{
+    size_t bytes = 0;
+    FCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, in, out, (int)n, 0, 64, st));
+    FCHK(tmp.need(bytes));
+    return hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, in, out, (int)n, 0, 64, st);
+}
+
+// np.median of a sorted column
+double median_sorted(const std::vector<double> &mid, long long n) { return n % 2 ? mid[0] : (mid[0] + mid[1]) / 2.0; }
+
+}  // namespace
+
+// Fusion (+ optional filter).  depth/conf: [n_maps][H*W] float32 on the device; bgr: [n_maps][H*W][3]
+// uint8 on the device; Kinv: 9 doubles, poses: n_maps x 12 doubles (host).  Results stay on the
+// device in *pts_out / *rgb_out (hipMalloc'ed here, owned by the caller); counts[0] = raw points,
+// counts[1] = points after the filter.
+hipError_t fuse_filter(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
+                       const double *Kinv_h, const double *poses_h, float min_views, bool do_filter,
+                       double **pts_out, unsigned char **rgb_out, long long counts[2], hipStream_t st)
+{
+    *pts_out = nullptr; *rgb_out = nullptr; counts[0] = counts[1] = 0;
+    const long long n = (long long)n_maps * H * W;
+    if (n <= 0 || n > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    Scratch tmp, flag, sel, consts, cnt;
+    FCHK(flag.need(n));
+    FCHK(sel.need(sizeof(long long) * n));
+    FCHK(consts.need(sizeof(double) * (9 + 12 * n_maps)));
+    FCHK(cnt.need(sizeof(long long)));
+    double *d_Kinv = (double *)consts.p, *d_poses = d_Kinv + 9;
+    FCHK(hipMemcpyAsync(d_Kinv, Kinv_h, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+    FCHK(hipMemcpyAsync(d_poses, poses_h, sizeof(double) * 12 * n_maps, hipMemcpyHostToDevice, st));
+
+    // ---- fusion: np.where(confidence >= min_views), view by view, row-major ----
+    hipLaunchKernelGGL(fuse_flag_kernel, grid_for(n), dim3(256), 0, st, conf, n, min_views, (unsigned char *)flag.p);
+    long long m = 0;
+    FCHK(select_indices((unsigned char *)flag.p, n, (long long *)sel.p, (long long *)cnt.p, &m, tmp, st));
+    counts[0] = counts[1] = m;
+    if (m == 0) return hipSuccess;
+    double *pts = nullptr;
+    unsigned char *rgb = nullptr;
+    FCHK(hipMalloc(&pts, sizeof(double) * 3 * m));
+    hipError_t e = hipMalloc(&rgb, 3 * m);
+    if (e != hipSuccess) { (void)hipFree(pts); return e; }
+    hipLaunchKernelGGL(fuse_project_kernel, grid_for(m), dim3(256), 0, st, (const long long *)sel.p, m, depth, bgr, H,
+                       W, d_Kinv, d_poses, pts, rgb);
+    auto bail = [&](hipError_t err) { (void)hipFree(pts); (void)hipFree(rgb); return err; };
+    if (!do_filter) {
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return bail(e);
+        *pts_out = pts; *rgb_out = rgb;
+        return hipSuccess;
+    }
+
+    // ---- filter: 95th-percentile radius around the per-axis median ----
+    Scratch colA, colB;
+    if ((e = colA.need(sizeof(double) * m)) != hipSuccess) return bail(e);
+    if ((e = colB.need(sizeof(double) * m)) != hipSuccess) return bail(e);
+    double centroid[3];
+    const long long lo = (m - 1) / 2;                         // middle element(s) of a sorted column
+    for (int c = 0; c < 3; ++c) {
+        hipLaunchKernelGGL(column_kernel, grid_for(m), dim3(256), 0, st, pts, m, c, (double *)colA.p);
+        if ((e = sort_keys((double *)colA.p, (double *)colB.p, m, tmp, st)) != hipSuccess) return bail(e);
+        std::vector<double> mid(2, 0.0);
+        if ((e = hipMemcpyAsync(mid.data(), (double *)colB.p + lo, sizeof(double) * (m % 2 ? 1 : 2),
+                                hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e);
+        centroid[c] = median_sorted(mid, m);
+    }
+    hipLaunchKernelGGL(dist_kernel, grid_for(m), dim3(256), 0, st, pts, m, centroid[0], centroid[1], centroid[2],
+                       (double *)colA.p);
+    if ((e = sort_keys((double *)colA.p, (double *)colB.p, m, tmp, st)) != hipSuccess) return bail(e);
+    // np.percentile(d, 95), method 'linear': virtual index 0.95*(m-1), numpy's _lerp
+    double thr;
+    {
+        const double vi = (95.0 / 100.0) * (double)(m - 1);
+        long long prev = (long long)std::floor(vi);
+        if (prev > m - 1) prev = m - 1;
+        const long long next = prev + 1 < m ? prev + 1 : m - 1;
+        const double t = vi - (double)prev;
+        double ab[2];
+        if ((e = hipMemcpyAsync(&ab[0], (double *)colB.p + prev, sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
+        if ((e = hipMemcpyAsync(&ab[1], (double *)colB.p + next, sizeof(double), hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e);
+        const double diff = ab[1] - ab[0];
+        thr = t >= 0.5 ? ab[1] - diff * (1.0 - t) : ab[0] + diff * t;
+    }
+    hipLaunchKernelGGL(below_kernel, grid_for(m), dim3(256), 0, st, (const double *)colA.p, m, thr, (unsigned char *)flag.p);
+    long long m2 = 0;
+    if ((e = select_indices((unsigned char *)flag.p, m, (long long *)sel.p, (long long *)cnt.p, &m2, tmp, st)) != hipSuccess) return bail(e);
+    if (m2 == 0) { (void)hipFree(pts); (void)hipFree(rgb); counts[1] = 0; return hipSuccess; }
+
+    // ---- voxel de-duplication: first point of every key, in key order ----
+    Scratch keysA, keysB, idxA, idxB, pick;
+    if ((e = keysA.need(8 * m2)) != hipSuccess || (e = keysB.need(8 * m2)) != hipSuccess ||
+        (e = idxA.need(8 * m2)) != hipSuccess || (e = idxB.need(8 * m2)) != hipSuccess ||
+        (e = pick.need(8 * m2)) != hipSuccess) return bail(e);
+    hipLaunchKernelGGL(voxel_key_kernel, grid_for(m2), dim3(256), 0, st, pts, (const long long *)sel.p, m2, 0.01,
+                       (long long *)keysA.p);
+    hipLaunchKernelGGL(iota_kernel, grid_for(m2), dim3(256), 0, st, (long long *)idxA.p, m2);
+    {
+        size_t bytes = 0;
+        if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (long long *)keysA.p, (long long *)keysB.p,
+                                                    (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st)) != hipSuccess) return bail(e);
+        if ((e = tmp.need(bytes)) != hipSuccess) return bail(e);
+        if ((e = hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, (long long *)keysA.p, (long long *)keysB.p,
+                                                    (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st)) != hipSuccess) return bail(e);
+    }
+    hipLaunchKernelGGL(run_head_kernel, grid_for(m2), dim3(256), 0, st, (const long long *)keysB.p, m2, (unsigned char *)flag.p);
+    long long m3 = 0;
+    {   // positions (in sorted order) of the run heads -> original indices idxB[pos]
+        size_t bytes = 0;
+        if ((e = hipcub::DeviceSelect::Flagged(nullptr, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
+                                               (long long *)pick.p, (long long *)cnt.p, (int)m2, st)) != hipSuccess) return bail(e);
+        if ((e = tmp.need(bytes)) != hipSuccess) return bail(e);
+        if ((e = hipcub::DeviceSelect::Flagged(tmp.p, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
+                                               (long long *)pick.p, (long long *)cnt.p, (int)m2, st)) != hipSuccess) return bail(e);
+        if ((e = hipMemcpyAsync(&m3, cnt.p, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e);
+    }
+    double *pts2 = nullptr;
+    unsigned char *rgb2 = nullptr;
+    if ((e = hipMalloc(&pts2, sizeof(double) * 3 * m3)) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&rgb2, 3 * m3)) != hipSuccess) { (void)hipFree(pts2); return bail(e); }
+    hipLaunchKernelGGL(gather_kernel, grid_for(m3), dim3(256), 0, st, pts, rgb, (const long long *)sel.p,
+                       (const long long *)pick.p, m3, pts2, rgb2);
+    e = hipStreamSynchronize(st);
+    (void)hipFree(pts); (void)hipFree(rgb);
+    if (e != hipSuccess) { (void)hipFree(pts2); (void)hipFree(rgb2); return e; }
+    *pts_out = pts2; *rgb_out = rgb2;
+    counts[1] = m3;
+    return hipSuccess;
+}
+
+}  // namespace amvs

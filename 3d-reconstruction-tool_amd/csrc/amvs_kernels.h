@@ -70,4 +70,9 @@ hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st);
 hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw, long long n,
                            float *u_out, float *n_out, hipStream_t st);
 
+// amvs_fusion.hip: fusion (+ filter) of per-view maps into a cloud; results are hipMalloc'ed
+hipError_t fuse_filter(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
+                       const double *Kinv_h, const double *poses_h, float min_views, bool do_filter,
+                       double **pts_out, unsigned char **rgb_out, long long counts[2], hipStream_t st);
+
 }  // namespace amvs

@@ -197,6 +197,38 @@ class Engine:
         self._chk(self._lib.amvs_box_stats(self._h, int(view), int(patch_size), _p(m), _p(v)))
         return m, v
 
+    # -- fusion / filter ----------------------------------------------------
+    def fuse_filter(self, depth, conf, colors_bgr, K_inv64, poses, min_views, do_filter=True, device_ptrs=None):
+        """Device fusion (+ filter): depth/conf (n,H,W) float32 host arrays -- or, with
+        device_ptrs=(depth_ptr, conf_ptr, n), maps already resident on the GPU --, colors (n,H,W,3)
+        uint8 BGR, poses = list of (R, t) float64.  Returns (points (M,3) float64, colors (M,3)
+        uint8 RGB, raw_count)."""
+        if device_ptrs is None:
+            depth = _f32(depth)
+            conf = _f32(conf)
+            n = depth.shape[0]
+            dptr, cptr, on_dev = depth.ctypes.data_as(C.c_void_p), conf.ctypes.data_as(C.c_void_p), 0
+        else:
+            dptr, cptr, n = C.c_void_p(device_ptrs[0]), C.c_void_p(device_ptrs[1]), int(device_ptrs[2])
+            on_dev = 1
+        cols = np.ascontiguousarray(colors_bgr, dtype=np.uint8).reshape(n, self.H, self.W, 3)
+        kinv = np.ascontiguousarray(K_inv64, dtype=np.float64).reshape(9)
+        pp = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(R, np.float64).reshape(9),
+                                                            np.asarray(t, np.float64).reshape(3)])
+                                            for R, t in poses]))
+        counts = (C.c_int64 * 2)()
+        self._chk(self._lib.amvs_fuse_filter(
+            self._h, n, dptr, cptr, on_dev,
+            cols.ctypes.data_as(C.POINTER(C.c_uint8)), kinv.ctypes.data_as(C.POINTER(C.c_double)),
+            pp.ctypes.data_as(C.POINTER(C.c_double)), float(min_views), int(bool(do_filter)), counts))
+        m = int(counts[1])
+        pts = np.empty((m, 3), np.float64)
+        rgb = np.empty((m, 3), np.uint8)
+        if m:
+            self._chk(self._lib.amvs_fetch_cloud(self._h, pts.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 rgb.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return pts, rgb, int(counts[0])
+
     def selftest_lean_math(self):
         """(reciprocal mismatches, sqrt mismatches) against IEEE over all 2^32 float patterns."""
         out = (C.c_uint64 * 2)()

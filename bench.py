@@ -232,23 +232,19 @@ def main():
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
             "confidence_ms_per_step": round(conf_ms / args.steps, 3),
         }
-        # "dense points/s": fuse + filter the maps of the last step on the host (untimed above;
-        # reference mvs_patchmatch.py:536-588) and relate the cloud to sweep + fusion time
+        # "dense points/s": fuse + filter the maps of the last step (untimed above) on the device
+        # (amvs_fuse_filter = mvs_patchmatch.py:536-588, bit-identical to the NumPy path) and relate
+        # the cloud to sweep + fusion time
         if world == 1:
+            torch.cuda.synchronize()
             t_f = time.perf_counter()
-            pmh = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
-            pmh.K_scaled, pmh.min_views = sc.camera.K.copy(), 3
-            dn, cf = depth.cpu().numpy(), conf.cpu().numpy()
-            maps = {r: amvs.DepthNormalMap(depth=dn[i], normal=None, confidence=cf[i]) for i, r in enumerate(refs)}
-            proc = {r: {"color": sc.colors[r]} for r in refs}
-            pts, cols = pmh._fuse_depth_maps(maps, proc, sc.poses)
-            raw = len(pts)
-            if raw:
-                pts, cols = pmh._filter_points(pts, cols)
+            pts, cols, raw = eng.fuse_filter(None, None, np.stack([sc.colors[r] for r in refs]),
+                                             np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in refs],
+                                             3, True, device_ptrs=(depth.data_ptr(), conf.data_ptr(), n_loc))
             t_f = time.perf_counter() - t_f
             out["dense_points"] = {"raw": raw, "final": int(len(pts)),
                                    "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),
-                                   "host_fusion_s": round(t_f, 3)}
+                                   "device_fusion_s": round(t_f, 4)}
         if world == 1 and not args.no_cpu_baseline:
             ref = n_views // 2
             out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources[ref], ref, sc.depth_min, sc.depth_max,

@@ -107,6 +107,19 @@ int amvs_plane_sweep_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const 
                             int n_nbr, const float *depths, int D, int patch_size,
                             float thresh, void *depth_dev, void *conf_dev);
 
+/* PatchMatchMVS._fuse_depth_maps + _filter_points (mvs_patchmatch.py:536-588) on the device, in
+ * float64 and in the reference's order: pixels with confidence >= min_views of n_maps maps
+ * ([n_maps][H][W] float32, host or device memory) are back-projected with the float64 K_inv and
+ * poses (n_maps x 12 doubles: R row-major then t); colours come from BGR uint8 images
+ * ([n_maps][H][W][3], host) and leave as RGB.  With do_filter: 95th-percentile radius cut around
+ * the per-axis median, then 1 cm voxel de-duplication keeping the first point of each voxel in
+ * key order.  counts[0] = fused points, counts[1] = points kept; amvs_fetch_cloud copies the
+ * counts[1] x 3 points (float64) and colours (uint8) to the host.                              */
+int amvs_fuse_filter(amvs_ctx *ctx, int n_maps, const void *depth, const void *conf, int maps_on_device,
+                     const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
+                     float min_views, int do_filter, int64_t counts[2]);
+int amvs_fetch_cloud(amvs_ctx *ctx, double *points_out, uint8_t *colors_out);
+
 /* ---- single-step entry points (parity tests drive these one reference call at a time) ---- */
 
 /* _compute_patch_cost (mvs_patchmatch.py:323-390): depth map in, averaged cost out. */

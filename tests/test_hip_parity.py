@@ -300,6 +300,60 @@ def test_non_8bit_images_use_float_path(amvs_mod):
         assert eng.sampling_mode() == "f32"
 
 
+# ------------------------------------------------------------------ fusion / filter ---
+def test_device_fusion_matches_reference_golden(eng_b, scene_b, amvs_mod):
+    """amvs_fuse_filter against the clouds the REFERENCE produced (g10): bit-identical points and
+    colours, raw and filtered."""
+    g = load_golden("g10_fuse_filter")
+    refs = [int(r) for r in g["refs"]]
+    depth = np.stack([scene_b.gt_depth[r] for r in refs])
+    cols = np.stack([scene_b.colors[r] for r in refs])
+    K_inv = np.linalg.inv(scene_b.K)
+    poses = [(scene_b.R[r], scene_b.t[r]) for r in refs]
+    pts, rgb, raw = eng_b.fuse_filter(depth, g["confidence"], cols, K_inv, poses, 3, do_filter=False)
+    assert raw == len(g["points"])
+    assert np.array_equal(pts, g["points"]) and np.array_equal(rgb, g["colors"])
+    fp, fc, raw2 = eng_b.fuse_filter(depth, g["confidence"], cols, K_inv, poses, 3, do_filter=True)
+    assert raw2 == raw
+    assert np.array_equal(fp, g["f_points"]) and np.array_equal(fc, g["f_colors"])
+
+
+def test_device_fusion_matches_numpy_on_sweep_output(amvs_mod):
+    """Fusion of real sweep output at a larger size (odd and even point counts, duplicate voxels):
+    device cloud == NumPy restatement of mvs_patchmatch.py:536-588."""
+    from amvs.core.mvs_patchmatch import DepthNormalMap, PatchMatchMVS
+    from amvs.synthetic import make_scene
+    sc = make_scene(5, 270, 480, seed=9)
+    pm = PatchMatchMVS(amvs_mod.Camera(K=sc.camera.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7)
+    with amvs_mod.Engine(270, 480, 5, sc.camera.K.astype(np.float32)) as eng:
+        for i in range(5):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        for min_views, drop in ((3, 0), (2, 1), (4, 0)):
+            maps, proc = {}, {}
+            for r in (1, 2, 3):
+                conf = eng.confidence(r, [i for i in range(5) if i != r], 7, sc.depths[r])
+                if drop:
+                    conf.flat[7] = 0.0                      # flip the parity of the point count
+                maps[r] = DepthNormalMap(depth=sc.depths[r], normal=None, confidence=conf)
+                proc[r] = {"color": sc.colors[r]}
+            pm.min_views = min_views
+            want_p, want_c = pm._fuse_depth_maps(maps, proc, sc.poses)
+            assert len(want_p) > 1000
+            want_fp, want_fc = pm._filter_points(want_p, want_c)
+            ids = list(maps)
+            got_p, got_c, raw = eng.fuse_filter(np.stack([maps[i].depth for i in ids]),
+                                                np.stack([maps[i].confidence for i in ids]),
+                                                np.stack([sc.colors[i] for i in ids]), np.linalg.inv(pm.K_scaled),
+                                                [(sc.poses[i].R, sc.poses[i].t) for i in ids], min_views, True)
+            assert raw == len(want_p)
+            assert len(want_fp) < len(want_p)                # the filter and the voxel grid removed points
+            assert np.array_equal(got_p, want_fp) and np.array_equal(got_c, want_fc)
+    empty = DepthNormalMap(depth=sc.depths[0], normal=None, confidence=np.zeros((270, 480), np.float32))
+    pm._engine = None
+    p0, c0 = pm._fuse_depth_maps({0: empty}, {0: {"color": sc.colors[0]}}, sc.poses)
+    assert p0.shape == (0, 3)
+
+
 # ------------------------------------------------------------------ error paths ---
 def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
