@@ -365,7 +365,8 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
 
         // ---- select (mvs_patchmatch.py:452-455 / :486-489) ----
         const float nx0 = n_in[3 * pc], nx1 = n_in[3 * pc + 1], nx2 = n_in[3 * pc + 2];
-        float candd, cn0, cn1, cn2;
+        const bool better = newc < oldc;
+        float candd, cn0 = nx0, cn1 = nx1, cn2 = nx2;
         if (mode == MODE_PROP) {
             // out-of-image neighbour: depth_min and a zero normal (F.pad, :431-442)
             const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
@@ -380,15 +381,18 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
             candd = d;
-            // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476)
-            float g0, g1, g2;
-            rng_normals3(h0c, g0, g1, g2);
-            cn0 = nx0 + g0 * a.normal_range;
-            cn1 = nx1 + g1 * a.normal_range;
-            cn2 = nx2 + g2 * a.normal_range;
-            normalize3(cn0, cn1, cn2);
+            // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476).  The perturbed normal is
+            // only ever read where the candidate wins: skip its Box-Muller + normalisation when no
+            // lane of the wave accepts (acceptance falls from 16 % to 1 % per pixel over a sweep)
+            if (__any(better)) {
+                float g0, g1, g2;
+                rng_normals3(h0c, g0, g1, g2);
+                cn0 = nx0 + g0 * a.normal_range;
+                cn1 = nx1 + g1 * a.normal_range;
+                cn2 = nx2 + g2 * a.normal_range;
+                normalize3(cn0, cn1, cn2);
+            }
         }
-        const bool better = newc < oldc;
         d_out[pc] = better ? candd : oldd;
         c_out[pc] = better ? newc : oldc;
         n_out[3 * pc] = better ? cn0 : nx0;

@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def profiled_traffic(kernel_key, workload_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, written by tools_profile_summary.py; FETCH_SIZE + WRITE_SIZE in KiB,
+    (profiles/traffic.json, written by tools/profile_summary.py; FETCH_SIZE + WRITE_SIZE in KiB,
     collected in separate passes, uncorrected -- MI355X_MICROARCH.md notes FETCH_SIZE can
     under-count wide streaming reads by 2x, dword gathers are uncalibrated).  None if no profile
     of this exact workload is committed."""

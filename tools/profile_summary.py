@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof (tools_profile.sh output) into a small text summary for profiles/."""
+"""Condense gpurun_out/prof (tools/profile.sh output) into a small text summary for profiles/."""
 import collections
 import csv
 import glob
@@ -10,7 +10,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "run"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 KF = sys.argv[3].split("<")[0].replace("_kernel", "") if len(sys.argv) > 3 else "pm_step"
 out = [f"# {tag}: {note}",
-       "# recipe: tools_profile.sh (rocprofv3 --kernel-trace --stats; separate --pmc passes)",
+       "# recipe: tools/profile.sh (rocprofv3 --kernel-trace --stats; separate --pmc passes)",
        "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
 st = sorted(glob.glob("gpurun_out/prof/trace/runc/*_kernel_stats.csv"), key=os.path.getmtime)[-1]
 for r in csv.DictReader(open(st)):
