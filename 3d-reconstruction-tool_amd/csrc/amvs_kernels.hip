@@ -20,6 +20,8 @@
 #include "amvs_kernels.h"
 #include "amvs_device.h"
 
+#include <cstdlib>
+
 namespace amvs {
 
 // The job table is never written while a sweep kernel runs: reading it through the
@@ -690,13 +692,21 @@ hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st)
 }
 
 // ------------------------------------------------------------------ dispatch -----
+// AMVS_DYN_LDS=<bytes>: experiment knob -- extra dynamic LDS per block caps the resident waves per
+// CU (160 KiB / bytes), to measure how throughput scales with occupancy
+static unsigned dyn_lds_bytes()
+{
+    static const unsigned v = [] { const char *e = std::getenv("AMVS_DYN_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
+    return v;
+}
+
 template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
     if (a.pairs)
-        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), dyn_lds_bytes(), st, a);
     else
-        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), dyn_lds_bytes(), st, a);
     return hipGetLastError();
 }
 template <int K, int S>

@@ -8,7 +8,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "run"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
-KF = sys.argv[3].split("<")[0].replace("_kernel", "") if len(sys.argv) > 3 else "pm_step"
+KF = (sys.argv[3].split("<")[0] + "<") if len(sys.argv) > 3 else "pm_step_kernel<"
 out = [f"# {tag}: {note}",
        "# recipe: tools/profile.sh (rocprofv3 --kernel-trace --stats; separate --pmc passes)",
        "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
@@ -45,7 +45,7 @@ if len(sys.argv) > 4:
         if fs:
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(sorted(fs, key=os.path.getmtime)[-1])):
-                if kernel_key.split("<")[0] in r["Kernel_Name"]:
+                if (kernel_key.split("<")[0] + "<") in r["Kernel_Name"]:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             for k, v in acc.items():
                 vals[k] = sum(v) / len(v)
