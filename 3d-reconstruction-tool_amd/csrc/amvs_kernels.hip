@@ -21,6 +21,7 @@
 #include "amvs_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace amvs {
 
@@ -118,29 +119,85 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
 //        row pipeline) at ~25 more VGPRs, so it is not the default.
 template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
 
+// Where the vertical rings live.  The ref ring and the rings of the first NL sources are kept in
+// LDS ([ring][slot][lane], rotating slot, conflict-free one-dword-per-lane accesses) instead of
+// registers: 7*(NL+1) fewer VGPRs held across the whole row loop (the sampling phase is the
+// register peak), which is what lets the k=7, S=4 kernel run five waves per SIMD; the other
+// sources stay in shifting register rings.
+#ifndef AMVS_RING_LDS_SOURCES
+#define AMVS_RING_LDS_SOURCES 2
+#endif
+template <int S> struct Ring {
+    static constexpr int NL = AMVS_RING_LDS_SOURCES < S ? AMVS_RING_LDS_SOURCES : S;   // sources in LDS
+    static constexpr int NR = S - NL > 0 ? S - NL : 1;                                  // register rings (>=1 for the type)
+    static constexpr bool REF_IN_LDS = NL > 0;
+};
+
+// per-row validity bits of the last K/2+1 rows packed into one (or two) registers
+template <int K, int S> struct Hist {
+    typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;
+};
+
 template <int K, int S>
-AMVS_DEV void window_sums(const float (&ring_r)[K], const float (&ring_v)[S][K], float4 *hbuf, int lane,
+AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], float (&ring_v)[Ring<S>::NR][K],
+                        float rv, const float (&v)[S])
+{
+    constexpr int NL = Ring<S>::NL;
+    if (Ring<S>::REF_IN_LDS) {
+        lring[wslot * AMVS_WAVE + lane] = rv;
+#pragma unroll
+        for (int s = 0; s < NL; ++s) lring[((s + 1) * K + wslot) * AMVS_WAVE + lane] = v[s];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring_r[i] = ring_r[i + 1];
+        ring_r[K - 1] = rv;
+    }
+#pragma unroll
+    for (int s = NL; s < S; ++s) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring_v[s - NL][i] = ring_v[s - NL][i + 1];
+        ring_v[s - NL][K - 1] = v[s];
+    }
+}
+
+// `oldest` = LDS slot of the oldest row (the next write slot once the ring is full)
+template <int K, int S>
+AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
+                          const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
                           float (&bv)[S], float (&bvv)[S], float (&brv)[S])
 {
     constexpr int NV4 = HSum<S>::NV4;
+    constexpr int NL = Ring<S>::NL;
     float cs[NV4 * 4];
 #pragma unroll
     for (int i = 0; i < NV4 * 4; ++i) cs[i] = 0.0f;
+    // ref values of the window, oldest -> newest
+    float rr[K];
+    int slot[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        slot[i] = oldest + i >= K ? oldest + i - K : oldest + i;
+        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[i];
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        float cv = ring_v[s][0];
-        float cvv = ring_v[s][0] * ring_v[s][0];
-        float crv = ring_r[0] * ring_v[s][0];
+        float vv[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            vv[i] = s < NL ? lring[((s + 1) * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][i];
+        float cv = vv[0];
+        float cvv = vv[0] * vv[0];
+        float crv = rr[0] * vv[0];
 #pragma unroll
         for (int i = 1; i < K; ++i) {
-            cv = cv + ring_v[s][i];
-            cvv = __builtin_fmaf(ring_v[s][i], ring_v[s][i], cvv);
-            crv = __builtin_fmaf(ring_r[i], ring_v[s][i], crv);
+            cv = cv + vv[i];
+            cvv = __builtin_fmaf(vv[i], vv[i], cvv);
+            crv = __builtin_fmaf(rr[i], vv[i], crv);
         }
         cs[3 * s] = cv; cs[3 * s + 1] = cvv; cs[3 * s + 2] = crv;
     }
 #ifndef AMVS_HSUM_LDS
-    (void)hbuf; (void)lane;
+    (void)hbuf;
     float acc[NV4 * 4];
 #pragma unroll
     for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
@@ -182,6 +239,10 @@ AMVS_DEV void window_sums(const float (&ring_r)[K], const float (&ring_v)[S][K],
 template <int K, int S>
 AMVS_DEV void window_sums_init(float4 *hbuf, int lane)
 {
+#ifndef AMVS_HSUM_LDS
+    (void)hbuf; (void)lane;
+    return;
+#endif
     constexpr int NV4 = HSum<S>::NV4;
     if (lane < K - 1)
 #pragma unroll
@@ -208,7 +269,12 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
     __shared__ float lut[256];
+    #ifdef AMVS_HSUM_LDS
     __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
+#else
+    float4 *hbuf = nullptr;
+#endif
+    __shared__ float lring[(Ring<S>::NL + 1) * K * AMVS_WAVE];
 
     const int lane = threadIdx.x;
     window_sums_init<K, S>(hbuf, lane);
@@ -250,17 +316,18 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     const int rows = min(a.TH, H - y0) + 2 * HALF;
 
     float ring_r[K];
-    float ring_v[S][K];
-    unsigned hist_ok[HALF + 1];
+    float ring_v[Ring<S>::NR][K];
+    typename Hist<K, S>::T hist_ok = 0;    // S validity bits per row, newest row in the top bits
     uint32_t hist_h0[HALF + 1];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         ring_r[i] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) ring_v[s][i] = 0.0f;
+        for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i <= HALF; ++i) { hist_ok[i] = 0u; hist_h0[i] = 0u; }
+    for (int i = 0; i <= HALF; ++i) hist_h0[i] = 0u;
+    int wslot = 0;                      // LDS ring slot the next row is written to
 
     // The candidate of pixel (y,x) is read at (y+oy, x+ox): the neighbour for a propagation step
     // (mvs_patchmatch.py:431-441), the pixel itself ((0,0)) for every other mode.  All loads use
@@ -302,18 +369,11 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
 
         // ---- push into the vertical rings ----
+        ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
+        wslot = wslot + 1 == K ? 0 : wslot + 1;          // now the slot of the oldest row
+        hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
 #pragma unroll
-        for (int i = 0; i < K - 1; ++i) {
-            ring_r[i] = ring_r[i + 1];
-#pragma unroll
-            for (int s = 0; s < S; ++s) ring_v[s][i] = ring_v[s][i + 1];
-        }
-        ring_r[K - 1] = rv;
-#pragma unroll
-        for (int s = 0; s < S; ++s) ring_v[s][K - 1] = v[s];
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) { hist_ok[i] = hist_ok[i + 1]; hist_h0[i] = hist_h0[i + 1]; }
-        hist_ok[HALF] = okbits;
+        for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
         hist_h0[HALF] = h0;
 
         if (r < 2 * HALF) continue;
@@ -326,11 +386,11 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const float m1 = mean1[pc], v1 = var1[pc];
         const float oldd = d_in[pc], oldc = c_in[pc];
         // the centre pixel was sampled by lane+HALF, HALF rows ago
-        const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
+        const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);     // low S bits: row r-HALF
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
 
         float bvs[S], bvvs[S], brvs[S];
-        window_sums<K, S>(ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
+        window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
 
         float total = 0.0f, cnt = 0.0f;
 #pragma unroll
@@ -417,7 +477,12 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     constexpr float INV_AREA = 1.0f / (float)(K * K);
     __shared__ uint32_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
     __shared__ float lut[256];
+    #ifdef AMVS_HSUM_LDS
     __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
+#else
+    float4 *hbuf = nullptr;
+#endif
+    __shared__ float lring[(Ring<S>::NL + 1) * K * AMVS_WAVE];
 
     const int lane = threadIdx.x;
     window_sums_init<K, S>(hbuf, lane);
@@ -452,16 +517,15 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[d];
         float ring_r[K];
-        float ring_v[S][K];
-        unsigned hist_ok[HALF + 1];
+        float ring_v[Ring<S>::NR][K];
+        typename Hist<K, S>::T hist_ok = 0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             ring_r[i] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < S; ++s) ring_v[s][i] = 0.0f;
+            for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
         }
-#pragma unroll
-        for (int i = 0; i <= HALF; ++i) hist_ok[i] = 0u;
+        int wslot = 0;
 
         for (int r = 0; r < rows; ++r) {
             const int yr = y0 - HALF + r;
@@ -473,29 +537,20 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
             float v[S];
             const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
-#pragma unroll
-            for (int i = 0; i < K - 1; ++i) {
-                ring_r[i] = ring_r[i + 1];
-#pragma unroll
-                for (int s = 0; s < S; ++s) ring_v[s][i] = ring_v[s][i + 1];
-            }
-            ring_r[K - 1] = rv;
-#pragma unroll
-            for (int s = 0; s < S; ++s) ring_v[s][K - 1] = v[s];
-#pragma unroll
-            for (int i = 0; i < HALF; ++i) hist_ok[i] = hist_ok[i + 1];
-            hist_ok[HALF] = okbits;
+            ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
+            wslot = wslot + 1 == K ? 0 : wslot + 1;
+            hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
             if (r < 2 * HALF) continue;
 
             const int yc = yr - HALF;
             const int xc = xr + HALF;
             const bool outl = (lane < OUTW) & (xc < W);
             const int pc = yc * W + xc;
-            const unsigned okc = (unsigned)__shfl_down((int)hist_ok[0], HALF);
+            const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
             float m1 = 0.0f, v1 = 0.0f;
             if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
             float bvs[S], bvvs[S], brvs[S];
-            window_sums<K, S>(ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
+            window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
             uint32_t votes = 0u;
 #pragma unroll
             for (int s = 0; s < S; ++s) {

@@ -229,6 +229,41 @@ def test_ragged_shapes_bit_exact(amvs_mod, shape):
             _eq(normal[0], on, f"{shape} k{k} normal")
 
 
+@pytest.mark.parametrize("shape,nviews,k,S", [((9, 11), 3, 3, 2), ((5, 70), 4, 5, 3), ((66, 7), 4, 7, 3),
+                                               ((40, 90), 7, 11, 6), ((30, 64), 7, 9, 5), ((24, 58), 7, 5, 6)])
+def test_tiny_and_wide_source_sets_bit_exact(amvs_mod, shape, nviews, k, S):
+    """Images smaller than one strip / one patch, single-column strips, and the widest source set
+    with the largest patch (K=11, S=6: 64-bit validity history): still bit-exact."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    H, W = shape
+    sc = make_scene(nviews, H, W, seed=H * 7 + W)
+    g8 = [np.round(g * 255.0).astype(np.uint8) for g in sc.grays]
+    grays = [g.astype(np.float32) / np.float32(255.0) for g in g8]          # 8-bit: packed sampling path
+    K = sc.camera.K.astype(np.float32)
+    ref = nviews // 2
+    srcs = [i for i in range(nviews) if i != ref][:S]
+    with amvs_mod.Engine(H, W, nviews, K) as eng:
+        for i in range(nviews):
+            eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "u8-pairs"
+        p = make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max)
+        depth, normal, conf = eng.patchmatch([ref], [srcs], p, 3)
+        ctx = oracle.ViewContext(K, grays[ref], sc.poses[ref].R, sc.poses[ref].t, [grays[i] for i in srcs],
+                                 [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k)
+        od, on, oc = ctx.patchmatch(2, 2, sc.depth_min, sc.depth_max, 3, ref)
+        _eq(depth[0], od, "depth")
+        _eq(conf[0], oc, "confidence")
+        _eq(normal[0], on, "normal")
+        if k in (5, 7) and S >= 2:
+            depths = (1.0 / np.linspace(1 / sc.depth_max, 1 / sc.depth_min, 9)).astype(np.float32)
+            d, c = eng.plane_sweep(ref, srcs, depths, k, 0.8)
+            wd, wc = ctx.plane_sweep(depths, 0.8)
+            _eq(d, wd, "sweep depth")
+            _eq(c, wc, "sweep confidence")
+
+
 # --------------------------------------------------- full-size, size-independent ----
 def test_full_size_invariants(amvs_mod):
     """1920x1080 (BASELINE config 3 resolution): results do not depend on the strip height,
