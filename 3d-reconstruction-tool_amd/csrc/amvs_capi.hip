@@ -305,7 +305,7 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     *out = nullptr;
     if (H < 2 || W < 2 || n_views < 1 || !K || !K_inv)
         return fail(nullptr, AMVS_EINVAL, "bad image size / view count / intrinsics");
-    if ((long long)H * W > (1ll << 30)) return fail(nullptr, AMVS_EINVAL, "image too large");
+    if ((long long)H * W > (1ll << 29)) return fail(nullptr, AMVS_EINVAL, "image too large (H*W must stay below 2^29: 32-bit pixel indices, 3 per normal)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, AMVS_EHIP, "no HIP device available (this backend has no CPU fallback)");
@@ -798,6 +798,34 @@ int amvs_fetch_cloud(amvs_ctx *c, double *points, uint8_t *colors)
     HIPCHK(c, hipMemcpyAsync(colors, c->d_cloud_rgb, 3 * c->cloud_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMVS_OK;
+}
+
+// utils.save_ply (utils.py:8-37): ASCII PLY, "%.6f %.6f %.6f %d %d %d" per vertex.  Host-only:
+// formats into a 1 MiB buffer instead of one Python f.write per point.
+int amvs_write_ply(const char *path, const double *points, const int64_t *colors, int64_t n)
+{
+    if (!path || n < 0 || (n > 0 && (!points || !colors))) return fail(nullptr, AMVS_EINVAL, "bad argument");
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(nullptr, AMVS_EINVAL, std::string("cannot open ") + path);
+    std::vector<char> buf(1 << 20);
+    size_t used = (size_t)std::snprintf(buf.data(), buf.size(),
+                                        "ply\nformat ascii 1.0\nelement vertex %lld\nproperty float x\n"
+                                        "property float y\nproperty float z\nproperty uchar red\n"
+                                        "property uchar green\nproperty uchar blue\nend_header\n",
+                                        (long long)n);
+    bool ok = true;
+    for (int64_t i = 0; i < n && ok; ++i) {
+        if (used + 256 > buf.size()) {
+            ok = std::fwrite(buf.data(), 1, used, f) == used;
+            used = 0;
+        }
+        used += (size_t)std::snprintf(buf.data() + used, 256, "%.6f %.6f %.6f %lld %lld %lld\n", points[3 * i],
+                                      points[3 * i + 1], points[3 * i + 2], (long long)colors[3 * i],
+                                      (long long)colors[3 * i + 1], (long long)colors[3 * i + 2]);
+    }
+    if (ok && used) ok = std::fwrite(buf.data(), 1, used, f) == used;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? AMVS_OK : fail(nullptr, AMVS_EINVAL, std::string("write failed: ") + path);
 }
 
 int amvs_selftest_lean_math(amvs_ctx *c, uint64_t mismatches[2])

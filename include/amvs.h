@@ -153,6 +153,11 @@ int amvs_box_stats(amvs_ctx *ctx, int view, int patch_size, float *mean_out, flo
 int amvs_rng_fill(amvs_ctx *ctx, uint64_t seed, uint32_t stream_view, uint32_t draw,
                   int64_t n, float *u_out, float *n_out);
 
+/* utils.save_ply (utils.py:8-37): ASCII PLY with "%.6f %.6f %.6f %d %d %d" per vertex; the same
+ * bytes as the reference writes, through one buffered native writer (no GPU involved; ctx-free).
+ * points: n x 3 float64, colors: n x 3 int64 (the reference casts with .astype(int)).          */
+int amvs_write_ply(const char *path, const double *points, const int64_t *colors, int64_t n);
+
 /* Self test: the kernels replace the IEEE divide / sqrt expansions by v_rcp_f32 / v_rsq_f32 with
  * FMA corrections (plus an IEEE path for out-of-range operands).  Compares both against
  * 1.0f/x and sqrtf(x) on ALL 2^32 float bit patterns; mismatches[0] = reciprocal,

@@ -335,6 +335,27 @@ def test_non_8bit_images_use_float_path(amvs_mod):
         assert eng.sampling_mode() == "f32"
 
 
+def test_4k_sweep_runs_and_is_tiling_invariant(amvs_mod):
+    """BASELINE config 5 resolution (3840x2160): indices, strides and the strip grid hold up."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    H, W = 2160, 3840
+    sc = make_scene(3, H, W, seed=4)
+    with amvs_mod.Engine(H, W, 3, sc.camera.K.astype(np.float32)) as eng:
+        for i in range(3):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        outs = []
+        for tr in (32, 16):
+            p = make_pm_params(7, 1, 1, sc.depth_min, sc.depth_max, tile_rows=tr)
+            outs.append(eng.patchmatch([1], [[0, 2]], p, 1))
+        for a, b, name in zip(outs[0], outs[1], ("depth", "normal", "confidence")):
+            _eq(a, b, f"4K {name}")
+        d = outs[0][0][0]
+        assert np.isfinite(d).all() and d.min() >= np.float32(sc.depth_min) and d.max() <= np.float32(sc.depth_max)
+        # the last rows / columns were written (not left at the allocation's garbage)
+        assert outs[0][2][0, -1, -1] in (0.0, 1.0, 2.0) and outs[0][2][0, -1, 0] in (0.0, 1.0, 2.0)
+
+
 # ------------------------------------------------------------------ fusion / filter ---
 def test_device_fusion_matches_reference_golden(eng_b, scene_b, amvs_mod):
     """amvs_fuse_filter against the clouds the REFERENCE produced (g10): bit-identical points and

@@ -155,3 +155,23 @@ def test_prepare_view_identity_scale_and_gray_formula():
     assert np.array_equal(out["gray"], gray8.astype(np.float32) / np.float32(255.0))
     half = prepare_view(img, 0.5)
     assert half["shape"] == (6, 8) and half["gray"].dtype == np.float32
+
+
+def test_save_ply_writes_the_reference_bytes(tmp_path):
+    """The native writer against a straight restatement of utils.save_ply (utils.py:20-35)."""
+    from amvs.core.utils import save_ply
+    rng = np.random.default_rng(3)
+    pts = np.concatenate([rng.normal(0, 3, (5000, 3)), rng.normal(0, 1e-7, (50, 3)), rng.normal(0, 1e6, (50, 3)),
+                          np.array([[0.0, -0.0, 0.5], [1e-7, -4.9999995e-7, 123456.7890125]])])
+    cols = rng.integers(0, 256, (len(pts), 3), dtype=np.uint8)
+    want = ["ply", "format ascii 1.0", f"element vertex {len(pts)}", "property float x", "property float y",
+            "property float z", "property uchar red", "property uchar green", "property uchar blue", "end_header"]
+    for i in range(len(pts)):
+        x, y, z = pts[i]
+        r, g, b = cols[i].astype(int)
+        want.append(f"{x:.6f} {y:.6f} {z:.6f} {r} {g} {b}")
+    out = tmp_path / "sub" / "cloud.ply"
+    save_ply(pts, cols, str(out))
+    assert out.read_text() == "\n".join(want) + "\n"
+    save_ply(np.zeros((0, 3)), np.zeros((0, 3)), str(tmp_path / "empty.ply"))
+    assert (tmp_path / "empty.ply").read_text().count("\n") == 10
