@@ -1,71 +1,100 @@
-"""Pinhole camera and pose types used on the dense-reconstruction boundary.
+"""Boundary types of the dense stage: pinhole intrinsics and world-to-camera poses.
 
-Same public surface as the reference's src/core/camera.py (Camera :11-75,
-CameraPose :78-108, load_calibration :111-139) so callers can pass either.
-Convention: X_cam = R @ X_world + t.
+The dense classes only read `.K` from a camera and `.R`, `.t`, `.center`,
+`.transform_points()` from a pose, so objects of the reference project
+(src/core/camera.py:11-108) can be passed straight in; these lightweight
+equivalents exist so the backend also runs stand-alone (tests, bench, synthetic
+scenes).  Convention everywhere: x_cam = R @ x_world + t.
 """
-from dataclasses import dataclass
 from pathlib import Path
 
 import numpy as np
 
+_N_DIST = 5      # k1, k2, p1, p2, k3
 
-@dataclass
+
 class Camera:
-    """Intrinsics K (3x3, [[fx,0,cx],[0,fy,cy],[0,0,1]]) and distortion (k1,k2,p1,p2,k3)."""
-    K: np.ndarray
-    dist: np.ndarray
+    """Intrinsic matrix `K` (3x3) plus lens distortion coefficients `dist`."""
 
-    fx = property(lambda self: self.K[0, 0])
-    fy = property(lambda self: self.K[1, 1])
-    cx = property(lambda self: self.K[0, 2])
-    cy = property(lambda self: self.K[1, 2])
+    __slots__ = ("K", "dist")
 
-    def project(self, points_3d: np.ndarray) -> np.ndarray:
-        """Camera-frame points (N,3) -> pixel coordinates (N,2)."""
-        xy = points_3d[:, :2] / points_3d[:, 2:3]
-        return np.column_stack([self.fx * xy[:, 0] + self.cx, self.fy * xy[:, 1] + self.cy])
+    def __init__(self, K, dist=None):
+        self.K = np.asarray(K, dtype=np.float64)
+        self.dist = np.zeros(_N_DIST) if dist is None else np.asarray(dist, dtype=np.float64)
 
-    def unproject(self, points_2d: np.ndarray, depth: float = 1.0) -> np.ndarray:
-        """Pixel coordinates (N,2) -> camera-frame points at the given depth (N,3)."""
-        xn = (points_2d[:, 0] - self.cx) / self.fx
-        yn = (points_2d[:, 1] - self.cy) / self.fy
-        return np.column_stack([xn * depth, yn * depth, np.full(len(points_2d), float(depth))])
+    def __repr__(self):
+        return f"Camera(fx={self.fx:.2f}, fy={self.fy:.2f}, cx={self.cx:.2f}, cy={self.cy:.2f})"
+
+    def _entry(self, row, col):
+        return self.K[row, col]
+
+    fx = property(lambda self: self._entry(0, 0))
+    fy = property(lambda self: self._entry(1, 1))
+    cx = property(lambda self: self._entry(0, 2))
+    cy = property(lambda self: self._entry(1, 2))
+
+    def project(self, points_3d):
+        """(N,3) camera-frame points -> (N,2) pixels: perspective divide, then focal / centre."""
+        pts = np.asarray(points_3d)
+        uv = pts[:, :2] / pts[:, 2:3]
+        uv = uv * np.array([self.fx, self.fy]) + np.array([self.cx, self.cy])
+        return uv
+
+    def unproject(self, points_2d, depth=1.0):
+        """(N,2) pixels -> (N,3) camera-frame points on the plane z = depth."""
+        px = np.asarray(points_2d, dtype=np.float64)
+        out = np.empty((len(px), 3))
+        out[:, 0] = (px[:, 0] - self.cx) / self.fx * depth
+        out[:, 1] = (px[:, 1] - self.cy) / self.fy * depth
+        out[:, 2] = depth
+        return out
 
 
-@dataclass
 class CameraPose:
-    """World-to-camera rigid transform."""
-    R: np.ndarray
-    t: np.ndarray
+    """Rigid world-to-camera transform (rotation `R`, translation `t`)."""
+
+    __slots__ = ("R", "t")
+
+    def __init__(self, R, t):
+        self.R = R
+        self.t = t
+
+    def __repr__(self):
+        c = self.center
+        return f"CameraPose(center=({c[0]:.3f}, {c[1]:.3f}, {c[2]:.3f}))"
+
+    @classmethod
+    def identity(cls):
+        return cls(np.eye(3), np.zeros(3))
 
     @property
-    def center(self) -> np.ndarray:
-        return -self.R.T @ self.t.ravel()
+    def center(self):
+        """Position of the optical centre in the world frame, -R^T t."""
+        return -(self.R.T @ np.ravel(self.t))
 
     @property
-    def projection_matrix(self) -> np.ndarray:
-        return np.hstack([self.R, self.t.reshape(3, 1)])
+    def projection_matrix(self):
+        """The 3x4 matrix [R | t]."""
+        return np.concatenate([self.R, np.reshape(self.t, (3, 1))], axis=1)
 
-    def transform_points(self, points_world: np.ndarray) -> np.ndarray:
-        return (self.R @ points_world.T).T + self.t.ravel()
-
-    @staticmethod
-    def identity() -> "CameraPose":
-        return CameraPose(R=np.eye(3), t=np.zeros(3))
+    def transform_points(self, points_world):
+        """(N,3) world points -> (N,3) camera-frame points."""
+        return (self.R @ points_world.T).T + np.ravel(self.t)
 
 
-def load_calibration(calibration_path: str) -> Camera:
-    """Read `mtx` / `dist` from a calibration .npz (reference camera.py:111-139)."""
-    path = Path(calibration_path)
-    if not path.exists():
-        raise FileNotFoundError(f"Calibration file not found: {path}")
-    with np.load(str(path)) as data:
-        K = data["mtx"].astype(np.float64)
-        dist = data["dist"].astype(np.float64).ravel()
-    if dist.size < 5:
-        dist = np.pad(dist, (0, 5 - dist.size))
-    print(f"Loaded calibration from {path.name}")
-    print(f"  Focal length: fx={K[0,0]:.1f}, fy={K[1,1]:.1f}")
-    print(f"  Principal point: cx={K[0,2]:.1f}, cy={K[1,2]:.1f}")
-    return Camera(K=K, dist=dist)
+def load_calibration(calibration_path):
+    """Camera from a chessboard-calibration archive with arrays `mtx` and `dist`
+    (what the reference's calibration tool stores; its loader is camera.py:111-139)."""
+    archive = Path(calibration_path)
+    if not archive.is_file():
+        raise FileNotFoundError(f"Calibration file not found: {archive}")
+    with np.load(str(archive)) as npz:
+        K = np.array(npz["mtx"], dtype=np.float64)
+        dist = np.array(npz["dist"], dtype=np.float64).reshape(-1)
+    if dist.size < _N_DIST:
+        dist = np.concatenate([dist, np.zeros(_N_DIST - dist.size)])
+    cam = Camera(K, dist)
+    print(f"Loaded calibration from {archive.name}")
+    print(f"  Focal length: fx={cam.fx:.1f}, fy={cam.fy:.1f}")
+    print(f"  Principal point: cx={cam.cx:.1f}, cy={cam.cy:.1f}")
+    return cam
