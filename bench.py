@@ -13,7 +13,8 @@ resident in HBM.  Workload at N=1: BASELINE config 3 -- 16 views of 1920x1080, 7
 4 sources, 8 iterations.  For N>1 every rank sweeps its own block of 16 views of a 16*N-view
 scene (weak scaling; all images replicated on every GPU because source sets cross shard
 boundaries) and the per-view maps (depth, normal, confidence: 20 B/pixel) are all-gathered
-over RCCL inside the timed step.
+over RCCL inside the timed step (in two batches per step, the exchange of the first overlapping the
+sweep of the second).
 
 Prints ONE JSON line (rank 0) with the throughput in Mpixel-hypotheses/s, the HBM-roofline
 figure of the dominant kernel (pm_step_kernel<7,4>, timed with HIP events on its own stream
@@ -87,6 +88,9 @@ def main():
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="sweeps per step (N>1: the all-gather of one batch overlaps the sweep of the next); "
+                         "0 = 1 on one GPU, 2 otherwise")
     ap.add_argument("--workload", choices=["patchmatch", "planesweep"], default="patchmatch")
     ap.add_argument("--planes", type=int, default=64)
     args = ap.parse_args()
@@ -117,7 +121,7 @@ def main():
 
     import amvs
     from amvs.engine import make_pm_params
-    from amvs.parallel import allgather_packed, shard
+    from amvs.parallel import shard
     from amvs.synthetic import make_scene
 
     H, W, vpg = args.height, args.width, args.views_per_gpu
@@ -149,17 +153,39 @@ def main():
     refs = list(mine)
     srcs = [sources[r] for r in refs]
 
+    # N>1: the rank's views are swept in `nb` batches; the RCCL all-gather of batch b runs on its
+    # own stream while batch b+1 is swept, so only the last batch's exchange is exposed
+    nb = args.batches if args.batches > 0 else (1 if world == 1 else 2)
+    nb = max(1, min(nb, n_loc))
+    bounds = [(b * n_loc) // nb for b in range(nb + 1)]
+    comm_stream = torch.cuda.Stream(device=dev)
+
     def step():
-        eng.patchmatch_device(refs, srcs, params, 42, depth.data_ptr(), normal.data_ptr(), conf.data_ptr())
-        if world > 1:
-            with torch.cuda.stream(stream):
-                packed = torch.cat([depth.reshape(n_loc, -1), normal.reshape(n_loc, -1),
-                                    conf.reshape(n_loc, -1)], dim=1)
-                if backend != "nccl":
-                    stream.synchronize()
-                    packed = packed.cpu()
-                gathered[0] = allgather_packed(packed, n_views, 5 * H * W)
+        works, parts = [], []
+        for b in range(nb):
+            lo, hi = bounds[b], bounds[b + 1]
+            eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[lo:hi].data_ptr(),
+                                  normal[lo:hi].data_ptr(), conf[lo:hi].data_ptr())
+            if world > 1:
+                done = torch.cuda.Event()
+                done.record(stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(done)
+                    packed = torch.cat([depth[lo:hi].reshape(hi - lo, -1), normal[lo:hi].reshape(hi - lo, -1),
+                                        conf[lo:hi].reshape(hi - lo, -1)], dim=1)
+                    if backend != "nccl":
+                        comm_stream.synchronize()
+                        packed = packed.cpu()
+                    # every rank contributes the same batch bounds: gather (hi-lo) rows per rank
+                    recv = torch.empty((world * (hi - lo), 5 * H * W), dtype=torch.float32, device=packed.device)
+                    works.append(dist.all_gather_into_tensor(recv, packed.contiguous(), async_op=True))
+                    parts.append((lo, hi, recv, packed))
         eng.sync()
+        for w in works:
+            w.wait()
+        if world > 1:
+            comm_stream.synchronize()
+            gathered[0] = parts
 
     gathered = [None]
 
@@ -178,28 +204,32 @@ def main():
     for _ in range(args.steps):
         step()
         t = eng.timing()
-        sweep_ms += t["sweep_ms"]
-        conf_ms += t["confidence_ms"]
-        launches += t["sweep_launches"]
+        sweep_ms += t["sweep_ms"] * nb            # timing of the last batch; batches are equal-sized
+        conf_ms += t["confidence_ms"] * nb
+        launches += t["sweep_launches"] * nb
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # every rank must now hold every view's maps: its own block is checked bit for bit
-        g = gathered[0]
-        assert g is not None and tuple(g.shape) == (n_views, 5 * H * W)
-        mine_rows = g[mine[0]: mine[0] + n_loc].to(dev)
-        assert torch.equal(mine_rows[:, : H * W], depth.reshape(n_loc, -1)), "all-gather: own depth block differs"
-        assert torch.equal(mine_rows[:, 4 * H * W:], conf.reshape(n_loc, -1)), "all-gather: own confidence block differs"
+        # every rank must now hold every view's maps: its own rows are checked bit for bit, and the
+        # rows of the other ranks must be populated
+        assert gathered[0] is not None and len(gathered[0]) == nb
+        for lo, hi, recv, _ in gathered[0]:
+            assert tuple(recv.shape) == (world * (hi - lo), 5 * H * W)
+            own = recv[rank * (hi - lo): (rank + 1) * (hi - lo)].to(dev)
+            assert torch.equal(own[:, : H * W], depth[lo:hi].reshape(hi - lo, -1)), "all-gather: own depth rows differ"
+            assert torch.equal(own[:, 4 * H * W:], conf[lo:hi].reshape(hi - lo, -1)), "all-gather: own confidence rows differ"
+            other = recv[((rank + 1) % world) * (hi - lo)].to(dev)
+            assert float(other[: H * W].min()) >= float(np.float32(sc.depth_min)) - 1e-3, "all-gather: peer rows empty"
 
     n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
     S = 4
     bytes_per_hyp = 4 * S + 44                       # 60 B at S=4
     launch_ms = sweep_ms / max(launches, 1)
-    algo_bytes_launch = bytes_per_hyp * n_loc * H * W
+    algo_bytes_launch = bytes_per_hyp * (bounds[nb] - bounds[nb - 1]) * H * W
     achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
     if rank == 0:
@@ -221,7 +251,7 @@ def main():
                                    f"{S} sources" + (f"; {n_views}-view scene, RCCL all-gather of maps" if world > 1 else ""),
                        "views_per_gpu": vpg, "width": W, "height": H, "patch": args.patch,
                        "iters": args.iters, "samples": args.samples, "sources": S,
-                       "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(),
+                       "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "batches_per_step": nb,
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
