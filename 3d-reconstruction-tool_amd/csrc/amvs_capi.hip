@@ -221,17 +221,21 @@ amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
     a.images = c->d_images;
     a.pairs = usable_pairs(c);
     a.pair_stride = c->pstride;
-    const Stats &s = c->stats.at(patch);
-    a.mean1 = s.mean; a.var1 = s.var;
     a.jobs = c->d_jobs;
     a.aux = c->d_aux;
     return a;
 }
 
-void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur)
+// depth buffer `cur_d` is read and cur_d^1 written on every step; cost lives in d_cost[0] and is
+// updated in place; normals: a propagation step reads buffer cur_n and writes cur_n^1, every other
+// mode works in place on cur_n
+void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur_d, int cur_n)
 {
-    a.d_in = c->d_depth[cur]; a.c_in = c->d_cost[cur]; a.n_in = c->d_normal[cur];
-    a.d_out = c->d_depth[cur ^ 1]; a.c_out = c->d_cost[cur ^ 1]; a.n_out = c->d_normal[cur ^ 1];
+    a.d_in = c->d_depth[cur_d];
+    a.d_out = c->d_depth[cur_d ^ 1];
+    a.cost = c->d_cost[0];
+    a.n_in = c->d_normal[cur_n];
+    a.n_out = a.mode == amvs::MODE_PROP ? c->d_normal[cur_n ^ 1] : c->d_normal[cur_n];
 }
 
 void resolve_timing(amvs_ctx *c)
@@ -265,10 +269,10 @@ int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     if ((rc = check_patch_src(c, patch, n_src))) return rc;
     if ((rc = ensure_slots(c, 1))) return rc;
     if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src))) return rc;
-    if ((rc = ensure_stats(c, patch))) return rc;
     o.c = c; o.patch = patch; o.n_src = n_src; o.hw = (size_t)c->H * c->W;
     o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64));
-    set_io(o.a, c, 0);
+    o.a.mode = amvs::MODE_EVAL;
+    set_io(o.a, c, 0, 0);
     return AMVS_OK;
 }
 
@@ -280,11 +284,11 @@ int upload_state(amvs_ctx *c, size_t hw, const float *depth, const float *normal
     return AMVS_OK;
 }
 
-int download_state(amvs_ctx *c, size_t hw, int buf, float *depth, float *normal, float *cost)
+int download_state(amvs_ctx *c, size_t hw, int dbuf, int nbuf, float *depth, float *normal, float *cost)
 {
-    HIPCHK(c, hipMemcpyAsync(depth, c->d_depth[buf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal, c->d_normal[buf], 12 * hw, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(cost, c->d_cost[buf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(depth, c->d_depth[dbuf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal, c->d_normal[nbuf], 12 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cost, c->d_cost[0], 4 * hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMVS_OK;
 }
@@ -445,7 +449,6 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if ((rc = check_patch_src(c, p->patch_size, n_src))) return rc;
     if ((rc = ensure_slots(c, n_ref))) return rc;
     if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src))) return rc;
-    if ((rc = ensure_stats(c, p->patch_size))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
     const int TH = pick_tile_rows(c, p->patch_size, n_src, n_ref, p->tile_rows, 1 << 20);
@@ -457,11 +460,11 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     c->timing = amvs_timing{};
 
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    int cur = 0;
+    int cur = 0, cur_n = 0;
     int64_t launches = 0;
     // initialisation (mvs_patchmatch.py:268-284)
     HIPCHK(c, amvs::launch_init(c->d_jobs, n_ref, (long long)hw, seed, p->log_depth_scale,
-                                p->log_depth_min, c->d_depth[cur], c->d_normal[cur], c->d_cost[cur],
+                                p->log_depth_min, c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0],
                                 c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     for (int it = 0; it < p->num_iterations; ++it) {
@@ -472,9 +475,9 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
             a.mode = amvs::MODE_PROP;
             a.oy = k == 0 ? sgn : 0;
             a.ox = k == 0 ? 0 : sgn;
-            set_io(a, c, cur);
+            set_io(a, c, cur, cur_n);
             HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-            cur ^= 1; ++launches;
+            cur ^= 1; cur_n ^= 1; ++launches;
         }
         // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
         a.mode = amvs::MODE_REFINE;
@@ -482,7 +485,7 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
         a.normal_range = (float)(0.5 * std::pow(0.5, it));
         for (int s = 0; s < p->num_samples; ++s) {
             a.draw = (unsigned)(1 + it * p->num_samples + s);
-            set_io(a, c, cur);
+            set_io(a, c, cur, cur_n);
             HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
             cur ^= 1; ++launches;
         }
@@ -490,12 +493,12 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
     a.mode = amvs::MODE_CONF;
-    set_io(a, c, cur);
+    set_io(a, c, cur, cur_n);
     a.aux = (float *)conf_dev;
     HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     c->timing.sweep_launches = launches;
     c->timing.pixel_hypotheses =
         (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
@@ -557,7 +560,6 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     if (rc) return rc;
     if ((rc = check_patch_src(c, patch_size, n_nbr))) return rc;
     if ((rc = upload_jobs(c, n_ref, ref_ids, nbr_ids, n_nbr))) return rc;
-    if ((rc = ensure_stats(c, patch_size))) return rc;
     if (D > c->cap_planes) {
         if (c->d_planes) (void)hipFree(c->d_planes);
         c->d_planes = nullptr; c->cap_planes = 0;
@@ -603,8 +605,6 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.images = c->d_images;
     a.pairs = usable_pairs(c);
     a.pair_stride = c->pstride;
-    const Stats &s = c->stats.at(patch_size);
-    a.mean1 = s.mean; a.var1 = s.var;
     a.depths = c->d_planes;
     a.thresh = thresh;
     a.depth_out = (float *)depth_dev; a.conf_out = (float *)conf_dev;
@@ -668,6 +668,7 @@ int amvs_confidence(amvs_ctx *c, int ref, const int *src_ids, int n_src, int pat
     if (!depth_in || !conf_out) return fail(c, AMVS_EINVAL, "NULL argument");
     if ((rc = upload_state(c, o.hw, depth_in, nullptr, nullptr))) return rc;
     o.a.mode = amvs::MODE_CONF;
+    set_io(o.a, c, 0, 0);
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
     HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * o.hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -683,9 +684,10 @@ int amvs_propagate_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int
     if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
     if ((rc = upload_state(c, o.hw, depth, normal, cost))) return rc;
     o.a.mode = amvs::MODE_PROP;
+    set_io(o.a, c, 0, 0);
     o.a.oy = oy; o.a.ox = ox; o.a.depth_min = depth_min;
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
-    return download_state(c, o.hw, 1, depth, normal, cost);
+    return download_state(c, o.hw, 1, 1, depth, normal, cost);
 }
 
 int amvs_refine_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size, float *depth,
@@ -702,11 +704,12 @@ int amvs_refine_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int pa
                              hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     o.a.mode = amvs::MODE_REFINE;
+    set_io(o.a, c, 0, 0);
     o.a.seed = seed; o.a.draw = draw;
     o.a.depth_range = depth_range; o.a.normal_range = normal_range;
     o.a.depth_min = depth_min; o.a.depth_max = depth_max;
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
-    return download_state(c, o.hw, 1, depth, normal, cost);
+    return download_state(c, o.hw, 1, 0, depth, normal, cost);
 }
 
 int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_depth_scale,
@@ -726,7 +729,7 @@ int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_
     const size_t hw = (size_t)c->H * c->W;
     HIPCHK(c, amvs::launch_init(c->d_jobs, 1, (long long)hw, seed, log_depth_scale, log_depth_min,
                                 c->d_depth[0], c->d_normal[0], c->d_cost[0], c->stream));
-    return download_state(c, hw, 0, depth, normal, cost);
+    return download_state(c, hw, 0, 0, depth, normal, cost);
 }
 
 int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float *var_out)

@@ -25,15 +25,23 @@ enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };
 // where the images live (common head of StepArgs and SweepArgs)
 struct StepArgsBase {
     long long img_stride;                    // floats between consecutive images
-    const float *images, *mean1, *var1;      // [n_views][img_stride]
+    const float *images;                     // float32 gray maps [n_views][img_stride]
     const uint16_t *pairs;                   // packed 8-bit row-pair maps [n_views][pair_stride], or NULL
     long long pair_stride;
 };
 
 struct StepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs;
-    const float *d_in, *c_in, *n_in;         // state read   [slot][H*W], normals [slot][H*W*3]
-    float *d_out, *c_out, *n_out;            // state written
+    // State [slot][H*W] (normals [slot][H*W*3]).  Depth is ping-ponged on every step (halo pixels
+    // of other strips read the pre-step map).  Cost and normals are only ever touched at a lane's
+    // own pixel: cost is updated in place; normals are updated in place by refinement steps (only
+    // where the candidate wins) and ping-ponged by propagation steps (the candidate is the
+    // NEIGHBOUR's pre-step normal).
+    const float *d_in;
+    float *d_out;
+    float *cost;
+    const float *n_in;                       // MODE_PROP only
+    float *n_out;                            // MODE_PROP: the other buffer; MODE_REFINE: the current one
     float *aux;                              // MODE_EVAL: cost map, MODE_CONF: confidence
     const Job *jobs;
     int mode, oy, ox;

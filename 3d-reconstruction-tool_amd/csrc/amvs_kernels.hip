@@ -51,6 +51,16 @@ AMVS_DEV JobCP reload(JobCP p)
 #define AMVS_SIDX(i) (i)
 #endif
 
+// Streaming state is touched once per launch; the packed source maps are re-read by every strip.
+// Non-temporal hints on the former keep them from evicting the latter from L2 / Infinity Cache.
+#ifdef AMVS_NT            // measured: no effect on MI355X (31.8 vs 31.7 G px-hyp/s), off by default
+#define AMVS_LDS_STREAM(p) __builtin_nontemporal_load(p)
+#define AMVS_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define AMVS_LDS_STREAM(p) (*(p))
+#define AMVS_ST_STREAM(p, v) (*(p) = (v))
+#endif
+
 // contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
 AMVS_DEV int xcd_remap(int bid, int nblk)
 {
@@ -164,7 +174,7 @@ AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], f
 template <int K, int S>
 AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
                           const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
-                          float (&bv)[S], float (&bvv)[S], float (&brv)[S])
+                          float (&bv)[S], float (&bvv)[S], float (&brv)[S], float &br, float &brr)
 {
     constexpr int NV4 = HSum<S>::NV4;
     constexpr int NL = Ring<S>::NL;
@@ -178,6 +188,18 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
     for (int i = 0; i < K; ++i) {
         slot[i] = oldest + i >= K ? oldest + i - K : oldest + i;
         rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[i];
+    }
+    // window sums of the reference image itself (r, r*r): the statistics mean1 / var1 of
+    // mvs_patchmatch.py:403,406, recomputed from the ring (same order as box_stats_kernel, so the
+    // same bits) instead of streaming two precomputed maps (8 B per pixel and step)
+    {
+        float cr = rr[0], crr = rr[0] * rr[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) { cr = cr + rr[i]; crr = __builtin_fmaf(rr[i], rr[i], crr); }
+        float ar = cr, arr = crr;
+#pragma unroll
+        for (int j = 1; j < K; ++j) { ar = wave_shl1(ar) + cr; arr = wave_shl1(arr) + crr; }
+        br = ar; brr = arr;
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -201,10 +223,12 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
     float acc[NV4 * 4];
 #pragma unroll
     for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
+#ifndef AMVS_ABL_NOHSUM      // timing-only: no horizontal pass
 #pragma unroll
     for (int j = 1; j < K; ++j)
 #pragma unroll
         for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
+#endif
 #else
     float4 *mine = hbuf + lane * NV4;
 #pragma unroll
@@ -291,14 +315,11 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     const long long HW = (long long)H * W;
 
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
-    const float *__restrict__ mean1 = a.mean1 + job->ref_img * a.img_stride;
-    const float *__restrict__ var1 = a.var1 + job->ref_img * a.img_stride;
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
-    const float *__restrict__ c_in = a.c_in + job->slot * HW;
     const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
-    float *__restrict__ c_out = a.c_out + job->slot * HW;
-    float *__restrict__ n_out = a.n_out + job->slot * HW * 3;
+    float *cost_io = a.cost + job->slot * HW;          // read and (where the candidate wins) written
+    float *n_out = a.n_out + job->slot * HW * 3;
     float *__restrict__ aux = a.aux + job->slot * HW;
 
     const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
@@ -346,14 +367,18 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];
-        const float r_raw = ref[AMVS_SIDX(live ? pix : 0)];
+        const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
+        const float r_raw = AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
         float dc = inb ? d_raw : a.depth_min;
         // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
+#ifdef AMVS_ABL_NOHASH       // timing-only
+        const uint32_t h0 = (uint32_t)pix * 2654435761u;
+#else
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
+#endif
         {
             float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
             float d = dc + delta;
@@ -383,14 +408,15 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = AMVS_SIDX(outl ? yc * W + xc : 0);
-        const float m1 = mean1[pc], v1 = var1[pc];
-        const float oldd = d_in[pc], oldc = c_in[pc];
+        const float oldd = d_in[pc], oldc = AMVS_LDS_STREAM(&cost_io[pc]);
         // the centre pixel was sampled by lane+HALF, HALF rows ago
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);     // low S bits: row r-HALF
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
 
-        float bvs[S], bvvs[S], brvs[S];
-        window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
+        float bvs[S], bvvs[S], brvs[S], br, brr;
+        window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
+        const float m1 = br * INV_AREA;
+        const float v1 = brr * INV_AREA - m1 * m1;
 
         float total = 0.0f, cnt = 0.0f;
 #pragma unroll
@@ -400,9 +426,13 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
             const float mean2 = bv * INV_AREA;
             const float var2 = bvv * INV_AREA - mean2 * mean2;
             const float cov = brv * INV_AREA - m1 * mean2;
+#ifdef AMVS_ABL_NONCC        // timing-only: no sqrt / divide
+            const float cost = cov + v1 * var2;
+#else
             const float den = sqrt_rn(v1 * var2) + 1e-8f;
             const float ncc = qdiv(cov, den, rcp_rn(den));
             const float cost = 1.0f - ncc;
+#endif
             const bool oks = (okc >> s) & 1u;
             // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
             const float ncc2 = 1.0f - cost;
@@ -426,40 +456,42 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         if (mode == MODE_EVAL) { aux[pc] = newc; continue; }
 
         // ---- select (mvs_patchmatch.py:452-455 / :486-489) ----
-        const float nx0 = n_in[3 * pc], nx1 = n_in[3 * pc + 1], nx2 = n_in[3 * pc + 2];
+        // HBM traffic is what bounds this kernel, so state is only moved where it
+        // has to be: depth goes to the other buffer for every pixel; cost is rewritten in place and
+        // only where the candidate wins; a refinement step reads and rewrites the normal in place and
+        // only where the candidate wins (4.5 % of the pixels on average).
         const bool better = newc < oldc;
-        float candd, cn0 = nx0, cn1 = nx1, cn2 = nx2;
+        if (better) cost_io[pc] = newc;
         if (mode == MODE_PROP) {
-            // out-of-image neighbour: depth_min and a zero normal (F.pad, :431-442)
+            // candidate = the neighbour's pre-step state; out-of-image neighbour: depth_min and a
+            // zero normal (F.pad, :431-442).  Normals are ping-ponged on these steps.
             const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
             const int pn = inb_c ? pc + noff : 0;
+            const int ps = better ? pn : pc;              // whose normal this pixel takes
             const float nb_d = d_in[pn];
-            const float nb0 = n_in[3 * pn], nb1 = n_in[3 * pn + 1], nb2 = n_in[3 * pn + 2];
-            candd = inb_c ? nb_d : a.depth_min;
-            cn0 = inb_c ? nb0 : 0.0f; cn1 = inb_c ? nb1 : 0.0f; cn2 = inb_c ? nb2 : 0.0f;
+            float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
+            const bool zero = better & !inb_c;
+            AMVS_ST_STREAM(&d_out[pc], better ? (inb_c ? nb_d : a.depth_min) : oldd);
+            AMVS_ST_STREAM(&n_out[3 * pc], zero ? 0.0f : t0);
+            AMVS_ST_STREAM(&n_out[3 * pc + 1], zero ? 0.0f : t1);
+            AMVS_ST_STREAM(&n_out[3 * pc + 2], zero ? 0.0f : t2);
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            candd = d;
-            // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476).  The perturbed normal is
-            // only ever read where the candidate wins: skip its Box-Muller + normalisation when no
-            // lane of the wave accepts (acceptance falls from 16 % to 1 % per pixel over a sweep)
-            if (__any(better)) {
+            AMVS_ST_STREAM(&d_out[pc], better ? d : oldd);
+            if (better) {
+                // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476)
                 float g0, g1, g2;
                 rng_normals3(h0c, g0, g1, g2);
-                cn0 = nx0 + g0 * a.normal_range;
-                cn1 = nx1 + g1 * a.normal_range;
-                cn2 = nx2 + g2 * a.normal_range;
+                float cn0 = n_out[3 * pc] + g0 * a.normal_range;
+                float cn1 = n_out[3 * pc + 1] + g1 * a.normal_range;
+                float cn2 = n_out[3 * pc + 2] + g2 * a.normal_range;
                 normalize3(cn0, cn1, cn2);
+                n_out[3 * pc] = cn0; n_out[3 * pc + 1] = cn1; n_out[3 * pc + 2] = cn2;
             }
         }
-        d_out[pc] = better ? candd : oldd;
-        c_out[pc] = better ? newc : oldc;
-        n_out[3 * pc] = better ? cn0 : nx0;
-        n_out[3 * pc + 1] = better ? cn1 : nx1;
-        n_out[3 * pc + 2] = better ? cn2 : nx2;
     }
 }
 
@@ -501,8 +533,6 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     const int H = a.H, W = a.W;
     const long long HW = (long long)H * W;
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
-    const float *__restrict__ mean1 = a.mean1 + job->ref_img * a.img_stride;
-    const float *__restrict__ var1 = a.var1 + job->ref_img * a.img_stride;
     const SampleConsts sc = make_sample_consts(H, W, -__builtin_inff(), __builtin_inff(), __builtin_inff());
 
     const int xbase = tx * OUTW - HALF;
@@ -545,12 +575,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const int yc = yr - HALF;
             const int xc = xr + HALF;
             const bool outl = (lane < OUTW) & (xc < W);
-            const int pc = yc * W + xc;
             const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
-            float m1 = 0.0f, v1 = 0.0f;
-            if (outl) { m1 = mean1[pc]; v1 = var1[pc]; }
-            float bvs[S], bvvs[S], brvs[S];
-            window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs);
+            float bvs[S], bvvs[S], brvs[S], br, brr;
+            window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
+            const float m1 = br * INV_AREA;
+            const float v1 = brr * INV_AREA - m1 * m1;
             uint32_t votes = 0u;
 #pragma unroll
             for (int s = 0; s < S; ++s) {

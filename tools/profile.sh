@@ -11,7 +11,8 @@ ARGS="bench.py --steps 1 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:---iters 2 --
 if [ -z "$PMC_ONLY" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ARGS > "$OUT/trace.log" 2>&1 || exit 1
 fi
-pmc() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1 || { echo "pmc $name failed"; tail -3 "$OUT/$name.log"; }; }
+# PMC_GROUPS="pmc_fetch pmc_write" restricts the passes
+pmc() { name=$1; shift; if [ -n "$PMC_GROUPS" ] && ! echo " $PMC_GROUPS " | grep -q " $name "; then return; fi; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $ARGS > "$OUT/$name.log" 2>&1 || { echo "pmc $name failed"; tail -3 "$OUT/$name.log"; }; }
 # (a TA_*/TCP_* group hung rocprofv3 on this pool once: not collected)
 pmc pmc_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 pmc pmc_sq2 SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_LDS
