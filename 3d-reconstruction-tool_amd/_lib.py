@@ -19,7 +19,7 @@ i32p = C.POINTER(C.c_int)
 
 class PmParams(C.Structure):
     _fields_ = [("patch_size", C.c_int32), ("num_iterations", C.c_int32),
-                ("num_samples", C.c_int32), ("tile_rows", C.c_int32),
+                ("num_samples", C.c_int32), ("tile_rows", C.c_int32), ("views_per_launch", C.c_int32),
                 ("depth_min", C.c_float), ("depth_max", C.c_float),
                 ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float)]
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "amvs_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "amvs_sampling_mode": (C.c_int, [C.c_void_p]),
     "amvs_last_tile_rows": (C.c_int, [C.c_void_p]),
+    "amvs_last_views_per_launch": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,
                                    C.c_float, f32p, f32p]),
     "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,

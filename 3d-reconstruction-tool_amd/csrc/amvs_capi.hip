@@ -59,7 +59,9 @@ struct amvs_ctx {
     long long cloud_n = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int last_tile_rows = 0;
+    int last_tile_rows = 0, last_views_per_launch = 0;
+    std::vector<hipEvent_t> ev_groups;   // per view group of the last PatchMatch call: init / steps / confidence
+    int timing_groups = 0;
     bool timing_pending = false;
     amvs_timing timing{};
     std::string err;
@@ -192,6 +194,16 @@ const uint16_t *usable_pairs(const amvs_ctx *c)
     return c->d_pairs;
 }
 
+// Views swept together by one launch.  Measured on MI355X (16 views 1080p, k=7, S=4, G px-hyp/s):
+// 1 view 20.0, 2: 26.3, 4: 28.5, 8: 30.9, 16: 31.8 -- filling the chip matters more than keeping a
+// small group's state resident in the Infinity Cache, so the default is the whole batch (capped so
+// that the per-launch state stays in the low GB).
+int default_views_per_launch(const amvs_ctx *c, int n_ref)
+{
+    (void)c;
+    return n_ref < 32 ? n_ref : 32;
+}
+
 // Rows per wave strip.  A strip re-samples 2*(patch/2) halo rows, so tall strips waste less, but
 // the launch needs several strips per resident wave slot to keep all CUs busy to the end.
 // Measured on MI355X (16 views 1080p, k=7): 16 rows 24.6, 32 rows 25.3-26.7, 64 rows 24.1-24.7,
@@ -241,16 +253,28 @@ void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur_d, int cur_n)
 void resolve_timing(amvs_ctx *c)
 {
     if (!c->timing_pending) return;
-    float ms0 = 0.f, ms1 = 0.f, ms2 = 0.f;
-    if (hipEventSynchronize(c->ev[3]) == hipSuccess) {
+    c->timing_pending = false;
+    if (hipEventSynchronize(c->ev[3]) != hipSuccess) return;
+    if (c->timing_groups > 0) {
+        // PatchMatch: per view group [start | init | steps | confidence]
+        double t_init = 0, t_sweep = 0, t_conf = 0;
+        hipEvent_t prev = c->ev[0];
+        for (int g = 0; g < c->timing_groups; ++g) {
+            float a = 0.f, b = 0.f, d = 0.f;
+            (void)hipEventElapsedTime(&a, prev, c->ev_groups[3 * g]);
+            (void)hipEventElapsedTime(&b, c->ev_groups[3 * g], c->ev_groups[3 * g + 1]);
+            (void)hipEventElapsedTime(&d, c->ev_groups[3 * g + 1], c->ev_groups[3 * g + 2]);
+            t_init += a; t_sweep += b; t_conf += d;
+            prev = c->ev_groups[3 * g + 2];
+        }
+        c->timing.init_ms = t_init; c->timing.sweep_ms = t_sweep; c->timing.confidence_ms = t_conf;
+    } else {
+        float ms0 = 0.f, ms1 = 0.f, ms2 = 0.f;
         (void)hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]);
         (void)hipEventElapsedTime(&ms1, c->ev[1], c->ev[2]);
         (void)hipEventElapsedTime(&ms2, c->ev[2], c->ev[3]);
+        c->timing.init_ms = ms0; c->timing.sweep_ms = ms1; c->timing.confidence_ms = ms2;
     }
-    c->timing.init_ms = ms0;
-    c->timing.sweep_ms = ms1;
-    c->timing.confidence_ms = ms2;
-    c->timing_pending = false;
 }
 
 // single-view, single-step helper for the test entry points
@@ -381,6 +405,7 @@ int amvs_destroy(amvs_ctx *c)
         if (kv.second.var) (void)hipFree(kv.second.var);
     }
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_groups) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return AMVS_OK;
@@ -451,57 +476,80 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
-    const int TH = pick_tile_rows(c, p->patch_size, n_src, n_ref, p->tile_rows, 1 << 20);
+    // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
+    // `vpl` views, each group through the whole schedule (see default_views_per_launch).
+    int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
+    if (const char *e = std::getenv("AMVS_VIEWS_PER_LAUNCH")) {
+        const int v = std::atoi(e);
+        if (v >= 1) vpl = v;
+    }
+    if (vpl > n_ref) vpl = n_ref;
+    const int TH = pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20);
     c->last_tile_rows = TH;
-    amvs::StepArgs a = base_args(c, p->patch_size, n_ref, TH);
-    a.depth_min = p->depth_min; a.depth_max = p->depth_max;
-    a.seed = seed;
     resolve_timing(c);
     c->timing = amvs_timing{};
+    const int n_groups = (n_ref + vpl - 1) / vpl;
+    // events: [0] start, then per group: after init, after steps, after confidence
+    while ((int)c->ev_groups.size() < 3 * n_groups) {
+        hipEvent_t ev;
+        HIPCHK(c, hipEventCreate(&ev));
+        c->ev_groups.push_back(ev);
+    }
+    c->timing_groups = n_groups;
 
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int cur = 0, cur_n = 0;
     int64_t launches = 0;
-    // initialisation (mvs_patchmatch.py:268-284)
-    HIPCHK(c, amvs::launch_init(c->d_jobs, n_ref, (long long)hw, seed, p->log_depth_scale,
-                                p->log_depth_min, c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0],
-                                c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    for (int it = 0; it < p->num_iterations; ++it) {
-        // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
-        // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
-        const int sgn = (it % 2 == 0) ? 1 : -1;
-        for (int k = 0; k < 2; ++k) {
-            a.mode = amvs::MODE_PROP;
-            a.oy = k == 0 ? sgn : 0;
-            a.ox = k == 0 ? 0 : sgn;
-            set_io(a, c, cur, cur_n);
-            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-            cur ^= 1; cur_n ^= 1; ++launches;
+    for (int g = 0; g < n_groups; ++g) {
+        const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
+        amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
+        a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
+        a.depth_min = p->depth_min; a.depth_max = p->depth_max;
+        a.seed = seed;
+        cur = 0; cur_n = 0;
+        // initialisation (mvs_patchmatch.py:268-284)
+        HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
+                                    c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g], c->stream));
+        for (int it = 0; it < p->num_iterations; ++it) {
+            // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
+            // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
+            const int sgn = (it % 2 == 0) ? 1 : -1;
+            for (int k = 0; k < 2; ++k) {
+                a.mode = amvs::MODE_PROP;
+                a.oy = k == 0 ? sgn : 0;
+                a.ox = k == 0 ? 0 : sgn;
+                set_io(a, c, cur, cur_n);
+                HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+                cur ^= 1; cur_n ^= 1; ++launches;
+            }
+            // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
+            a.mode = amvs::MODE_REFINE;
+            a.depth_range = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
+            a.normal_range = (float)(0.5 * std::pow(0.5, it));
+            for (int s = 0; s < p->num_samples; ++s) {
+                a.draw = (unsigned)(1 + it * p->num_samples + s);
+                set_io(a, c, cur, cur_n);
+                HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+                cur ^= 1; ++launches;
+            }
         }
-        // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
-        a.mode = amvs::MODE_REFINE;
-        a.depth_range = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
-        a.normal_range = (float)(0.5 * std::pow(0.5, it));
-        for (int s = 0; s < p->num_samples; ++s) {
-            a.draw = (unsigned)(1 + it * p->num_samples + s);
-            set_io(a, c, cur, cur_n);
-            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-            cur ^= 1; ++launches;
-        }
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 1], c->stream));
+        // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
+        a.mode = amvs::MODE_CONF;
+        set_io(a, c, cur, cur_n);
+        a.aux = (float *)conf_dev;
+        HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
     }
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
-    a.mode = amvs::MODE_CONF;
-    set_io(a, c, cur, cur_n);
-    a.aux = (float *)conf_dev;
-    HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    // every group ran the same schedule, so the final buffers (cur, cur_n) are the same for all
     HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->timing.sweep_launches = launches;
     c->timing.pixel_hypotheses =
         (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
+    c->last_views_per_launch = vpl;
     c->timing_pending = true;
     return AMVS_OK;
 }
@@ -549,6 +597,8 @@ int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
 int amvs_sampling_mode(const amvs_ctx *c) { return c && usable_pairs(c) ? 1 : 0; }
 
 int amvs_last_tile_rows(const amvs_ctx *c) { return c ? c->last_tile_rows : 0; }
+
+int amvs_last_views_per_launch(const amvs_ctx *c) { return c ? c->last_views_per_launch : 0; }
 
 int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
                             const float *depths, int D, int patch_size, float thresh, void *depth_dev,
@@ -612,6 +662,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.jobs = c->d_jobs;
     resolve_timing(c);
     c->timing = amvs_timing{};
+    c->timing_groups = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_keys, 0, sizeof(unsigned) * hw * n_ref, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

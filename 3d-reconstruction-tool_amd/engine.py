@@ -23,12 +23,13 @@ def _ids(a):
     return a, a.ctypes.data_as(i32p)
 
 
-def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0):
+def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0,
+                   views_per_launch=0):
     """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does."""
     log_min = np.log(float(depth_min))
     log_max = np.log(float(depth_max))
     return PmParams(int(patch_size), int(num_iterations), int(num_samples), int(tile_rows),
-                    float(depth_min), float(depth_max),
+                    int(views_per_launch), float(depth_min), float(depth_max),
                     float(np.float32(log_max - log_min)), float(np.float32(log_min)))
 
 
@@ -123,6 +124,9 @@ class Engine:
 
     def last_tile_rows(self):
         return int(self._lib.amvs_last_tile_rows(self._h))
+
+    def last_views_per_launch(self):
+        return int(self._lib.amvs_last_views_per_launch(self._h))
 
     # -- plane sweep -------------------------------------------------------
     def plane_sweep(self, ref, nbr_ids, depths, patch_size, thresh):

@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--views-per-launch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batches", type=int, default=0,
                     help="sweeps per step (N>1: the all-gather of one batch overlaps the sweep of the next); "
@@ -145,7 +146,8 @@ def main():
         sc.grays[i] = g.cpu().numpy()
         eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
         torch.cuda.synchronize()
-    params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows)
+    params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
+                            args.views_per_launch)
     n_loc = len(mine)
     depth = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
     normal = torch.empty((n_loc, H, W, 3), dtype=torch.float32, device=dev)
@@ -229,7 +231,8 @@ def main():
     S = 4
     bytes_per_hyp = 4 * S + 44                       # 60 B at S=4
     launch_ms = sweep_ms / max(launches, 1)
-    algo_bytes_launch = bytes_per_hyp * (bounds[nb] - bounds[nb - 1]) * H * W
+    vpl = eng.last_views_per_launch()
+    algo_bytes_launch = bytes_per_hyp * vpl * H * W          # views per launch x pixels x 60 B
     achieved = algo_bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
     if rank == 0:
@@ -251,13 +254,14 @@ def main():
                                    f"{S} sources" + (f"; {n_views}-view scene, RCCL all-gather of maps" if world > 1 else ""),
                        "views_per_gpu": vpg, "width": W, "height": H, "patch": args.patch,
                        "iters": args.iters, "samples": args.samples, "sources": S,
-                       "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "batches_per_step": nb,
+                       "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "views_per_launch": eng.last_views_per_launch(),
+                       "batches_per_step": nb,
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": profiled_traffic(f"pm_step_kernel<{args.patch},{S}>",
-                                                     f"{vpg}x{W}x{H}"),
+                                                     f"{vpl}x{W}x{H}"),
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
             "confidence_ms_per_step": round(conf_ms / args.steps, 3),

@@ -45,6 +45,7 @@ typedef struct {
     int32_t num_iterations;
     int32_t num_samples;
     int32_t tile_rows;        /* rows per wave strip; 0 = choose automatically    */
+    int32_t views_per_launch; /* views swept together (cache residency); 0 = auto  */
     float   depth_min, depth_max;
     float   log_depth_scale, log_depth_min;
 } amvs_pm_params;
@@ -96,6 +97,8 @@ int amvs_get_timing(const amvs_ctx *ctx, amvs_timing *out);
 int amvs_sampling_mode(const amvs_ctx *ctx);
 /* Rows per wave strip the last sweep used (amvs_pm_params.tile_rows, or the automatic choice). */
 int amvs_last_tile_rows(const amvs_ctx *ctx);
+/* Views per launch group the last PatchMatch call used (amvs_pm_params.views_per_launch or auto). */
+int amvs_last_views_per_launch(const amvs_ctx *ctx);
 
 /* DenseStereoReconstructor._plane_sweep_torch (dense_stereo.py:222-316) for one
  * reference view: D depth planes, votes (ncc > thresh) & (z > 0.1) over n_nbr

@@ -289,6 +289,12 @@ def test_full_size_invariants(amvs_mod):
                     _eq(a, b, f"tile_rows {tile_rows} {name}")
         p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max)
         both = eng.patchmatch([1, 2], [srcs[1], srcs[2]], p, 5)
+        assert eng.last_views_per_launch() == 2
+        split = eng.patchmatch([1, 2], [srcs[1], srcs[2]],
+                               make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max, views_per_launch=1), 5)
+        assert eng.last_views_per_launch() == 1
+        for a, b, name in zip(split, both, ("depth", "normal", "confidence")):
+            _eq(a, b, f"views_per_launch=1 {name}")
         for a, b, name in zip(both, base, ("depth", "normal", "confidence")):
             _eq(a[1], b[0], f"batched {name}")
         assert np.isfinite(base[0]).all() and base[0].min() >= np.float32(sc.depth_min) \
