@@ -315,6 +315,7 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     const long long HW = (long long)H * W;
 
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
+    const uint16_t *__restrict__ ref_pairs = a.pairs + (U8 ? job->ref_img * a.pair_stride : 0);
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
     const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
@@ -368,7 +369,10 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
         const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
-        const float r_raw = AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
+        // ref gray: in the packed path the low byte of the row-pair map decoded through the table
+        // (the same float as the float32 map holds, at half the bytes)
+        const float r_raw = U8 ? lut[ref_pairs[AMVS_SIDX(live ? pix : 0)] & 0xFFu]
+                               : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
