@@ -487,7 +487,7 @@ ORC_API void orc_propagate_step(orc_ctx_t *c, float *depth, float *normal, float
 {
     const int H = c->cam.H, W = c->cam.W;
     const size_t n = (size_t)H * W;
-    float *cd = (float *)malloc(sizeof(float) * n * 5);
+    float *cd = (float *)calloc(n * 5, sizeof(float));
     float *cn = cd + n, *cc = cd + 4 * n;
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
@@ -534,7 +534,7 @@ ORC_API void orc_refine_step(orc_ctx_t *c, float *depth, float *normal, float *c
                              float depth_min, float depth_max)
 {
     const size_t n = (size_t)c->cam.H * c->cam.W;
-    float *cd = (float *)malloc(sizeof(float) * n * 5);
+    float *cd = (float *)calloc(n * 5, sizeof(float));
     float *cn = cd + n, *cc = cd + 4 * n;
     for (size_t i = 0; i < n; ++i) {
         float delta = (u[i] * 2.0f - 1.0f) * depth_range;        /* :471 */
