@@ -115,7 +115,7 @@ int ensure_slots(amvs_ctx *c, int n)
     c->cap_slots = 0;
     for (int i = 0; i < 2; ++i) {
         HIPCHK(c, hipMalloc(&c->d_depth[i], sizeof(float) * hw * n));
-        HIPCHK(c, hipMalloc(&c->d_cost[i], sizeof(float) * hw * n));
+        if (i == 0) HIPCHK(c, hipMalloc(&c->d_cost[i], sizeof(float) * hw * n));   // cost is updated in place
         HIPCHK(c, hipMalloc(&c->d_normal[i], sizeof(float) * hw * n * 3));
     }
     HIPCHK(c, hipMalloc(&c->d_aux, sizeof(float) * hw * n));
