@@ -14,8 +14,17 @@ struct Job {
                             // the same in-loop scalar loads as the poses
     float Rref[9], tref[3];
     float Rs[AMVS_KMAX_SRC][9], ts[AMVS_KMAX_SRC][3];
+    // the same poses, two sources interleaved ([pair][entry][2]): one 64-bit scalar operand per
+    // matrix entry for the packed-fp32 projection of a source pair
+    float RsP[AMVS_KMAX_SRC / 2][9][2], tsP[AMVS_KMAX_SRC / 2][3][2];
+    // sampler constants, each duplicated into a pair for the same reason:
+    // W-1, H-1, RN(1/(W-1)), RN(1/(H-1)), (W-1)/2, (H-1)/2
+    float gridc[6][2];
     int ref_img;
     int src_img[AMVS_KMAX_SRC];
+    // device addresses of the source maps (packed 8-bit row pairs / float32 gray), so that the
+    // kernels do not rebuild base + index * stride on the scalar unit for every source and row
+    unsigned long long src_pairs[AMVS_KMAX_SRC], src_gray[AMVS_KMAX_SRC];
     uint32_t stream_view;   // RNG stream id (the reference view's index)
     int slot;               // state / output slot inside the batch buffers
 };

@@ -69,13 +69,85 @@ AMVS_DEV int xcd_remap(int bid, int nblk)
     return base + (bid >> 3);
 }
 
+// AMVS_TIMERS (measurement build only): per-wave cycle totals of the phases of a row, printed by a
+// few sampled waves.  ph 0: state loads + wait, 1: geometry, 2: gather wait, 3: decode + ring push,
+// 4: window sums + NCC (includes the wait for the old cost/depth), 5: select + stores.
+#ifdef AMVS_TIMERS
+struct Timers { unsigned long long acc[8]; unsigned long long last; };
+AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
+{
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    tm.acc[ph] += now - tm.last;
+    tm.last = now;
+}
+#define AMVS_TMARK(ph, drain) tmark(tm, ph, drain)
+#define AMVS_TM_PARAM , Timers &tm
+#define AMVS_TM_ARG , tm
+#else
+#define AMVS_TMARK(ph, drain)
+#define AMVS_TM_PARAM
+#define AMVS_TM_ARG
+#endif
+
+#ifndef AMVS_NO_PAIRS
+#define AMVS_NO_PAIRS 0
+#endif
+
+// Every scalar operand the sampling of one source (or source pair) needs, fetched as ONE batch of
+// scalar loads with a single wait: left to itself the compiler issues the pose, the intrinsics and
+// the image pointer in three separate load / wait rounds per source, and those serialised
+// scalar-cache latencies were ~10 % of the launch (timing ablation with immediates).
+struct SrcScalars { float K[6], R[9], t[3]; unsigned long long img; };
+AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
+{
+    SrcScalars c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.K[i] = jr->K[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = jr->Rs[s][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = jr->ts[s][i];
+    c.img = u8 ? jr->src_pairs[s] : jr->src_gray[s];
+#ifndef AMVS_NO_SMEM_BATCH
+    asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
+                 "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
+                 "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]), "+s"(c.img));
+#endif
+    return c;
+}
+
+struct PairScalars { float K[6]; v2f R[9], t[3], gc[6]; unsigned long long img[2]; };
+AMVS_DEV PairScalars load_pair_scalars(JobCP jr, int pr)
+{
+    PairScalars c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.K[i] = jr->K[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.R[i] = (v2f){jr->RsP[pr][i][0], jr->RsP[pr][i][1]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.t[i] = (v2f){jr->tsP[pr][i][0], jr->tsP[pr][i][1]};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c.gc[i] = (v2f){jr->gridc[i][0], jr->gridc[i][1]};
+    c.img[0] = jr->src_pairs[2 * pr];
+    c.img[1] = jr->src_pairs[2 * pr + 1];
+#ifndef AMVS_NO_SMEM_BATCH
+    asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
+                 "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
+                 "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]),
+                 "+s"(c.gc[0]), "+s"(c.gc[1]), "+s"(c.gc[2]), "+s"(c.gc[3]), "+s"(c.gc[4]), "+s"(c.gc[5]),
+                 "+s"(c.img[0]), "+s"(c.img[1]));
+#endif
+    return c;
+}
+
 // Sample all S sources of one pixel.  AMVS_PHASED: geometry of every source, then all gathers,
 // then decode (gathers issue back to back); default: source by source.  Same arithmetic either
 // way.  Measured on MI355X (16 views 1080p, k=7, S=4): source-by-source 26.9, phased 22.7 (128
 // VGPR) / 25.2 (147 VGPR) G px-hyp/s.
 template <int S, bool U8>
 AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                 Vec3 Pw, bool live, float (&v)[S])
+                                 Vec3 Pw, bool live, float (&v)[S] AMVS_TM_PARAM)
 {
     unsigned okbits = 0u;
     JobCP jr = job;
@@ -92,22 +164,40 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
     jr = reload(jr);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        const void *src = U8 ? (const void *)(a.pairs + jr->src_img[s] * a.pair_stride)
-                             : (const void *)(a.images + jr->src_img[s] * a.img_stride);
+        const void *src = (const void *)(U8 ? jr->src_pairs[s] : jr->src_gray[s]);
         tr[s] = sample_load<U8>(src, tg[s]);
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
 #else
+    constexpr int SP = (U8 && !AMVS_NO_PAIRS) ? (S & ~1) : 0;     // sources handled as pairs
+    if constexpr (U8) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < SP; s += 2) {
+            bool ok0, ok1;
+            jr = AMVS_SRC_RELOAD(jr);
+            const PairScalars c = load_pair_scalars(jr, s / 2);
+            const TapGeomPair tg = sample_geom_pair(c.K, c.R, c.t, c.gc, sc, Pw, live, ok0, ok1);
+            okbits |= (ok0 ? (1u << s) : 0u) | (ok1 ? (2u << s) : 0u);
+            uint32_t w0, w1;
+            __builtin_memcpy(&w0, (const char *)c.img[0] + 2 * tg.off[0], 4);
+            __builtin_memcpy(&w1, (const char *)c.img[1] + 2 * tg.off[1], 4);
+            AMVS_TMARK(1, false);
+            AMVS_TMARK(2, true);
+            const v2f vp = sample_finish_pair(w0, w1, tg, lut, live);
+            v[s] = vp.x; v[s + 1] = vp.y;
+        }
+    }
+#pragma unroll
+    for (int s = SP; s < S; ++s) {
         bool ok;
         jr = AMVS_SRC_RELOAD(jr);
-        const TapGeom<U8> tg = sample_geom<U8>(jr->K, jr->Rs[s], jr->ts[s], sc, Pw, live, ok);
+        const SrcScalars c = load_src_scalars(jr, s, U8);
+        const TapGeom<U8> tg = sample_geom<U8>(c.K, c.R, c.t, sc, Pw, live, ok);
         okbits |= ok ? (1u << s) : 0u;
-        const void *src = U8 ? (const void *)(a.pairs + jr->src_img[s] * a.pair_stride)
-                             : (const void *)(a.images + jr->src_img[s] * a.img_stride);
-        const TapRaw<U8> tr = sample_load<U8>(src, tg);
+        const TapRaw<U8> tr = sample_load<U8>((const void *)c.img, tg);
+        AMVS_TMARK(1, false);
+        AMVS_TMARK(2, true);
         v[s] = sample_finish<U8>(tr, tg, lut, live);
     }
 #endif
@@ -286,8 +376,34 @@ constexpr int min_waves(int K, int S)
     return ((S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_MIN_WAVES_BIAS;
 }
 
+// Normal update of `n` queued refinement winners (entries head .. head+n-1 of the ring `nq`), one
+// per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).
+AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *n_out, float normal_range)
+{
+    if (lane < n) {
+        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
+        float *np = n_out + 3ll * (int)e.x;
+        float g0, g1, g2;
+        rng_normals3(e.y, g0, g1, g2);
+        float cn0 = np[0] + g0 * normal_range;
+        float cn1 = np[1] + g1 * normal_range;
+        float cn2 = np[2] + g2 * normal_range;
+        normalize3(cn0, cn1, cn2);
+        np[0] = cn0; np[1] = cn1; np[2] = cn2;
+    }
+}
+
+// AMVS_WG_WAVES adjacent strips share one workgroup (one CU, started together), so the source
+// sectors their epipolar bands have in common are fetched while they are still in L1 / L2.
+#ifndef AMVS_WG_WAVES
+#define AMVS_WG_WAVES 1
+#endif
+#ifndef AMVS_WG_SYNC_ROWS          // barrier every this many rows keeps the strips in step (0: never)
+#define AMVS_WG_SYNC_ROWS 0
+#endif
+
 template <int K, int S, bool U8>
-__global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(const StepArgs a)
+__global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm_step_kernel(const StepArgs a)
 {
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
@@ -298,13 +414,26 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
 #else
     float4 *hbuf = nullptr;
 #endif
-    __shared__ float lring[(Ring<S>::NL + 1) * K * AMVS_WAVE];
+    __shared__ float lring_all[AMVS_WG_WAVES * (Ring<S>::NL + 1) * K * AMVS_WAVE];
+    constexpr int NQ = 2 * AMVS_WAVE;                    // refinement winners waiting for their normal
+    __shared__ uint2 nq_all[AMVS_WG_WAVES * NQ];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (AMVS_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
+    float *lring = lring_all + wv * ((Ring<S>::NL + 1) * K * AMVS_WAVE);
+    uint2 *nq = nq_all + wv * NQ;
+    int q_head = 0, q_tail = 0;                          // wave-uniform; at most 63 + 58 entries queued
     window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
+#ifdef AMVS_WG_SCATTER      // timing experiment: same workgroup shape, strips far apart
+    int t = xcd_remap(blockIdx.x, gridDim.x) + wv * (int)gridDim.x;
+#else
+    int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
+#endif
+    const bool idle_wave = t >= a.n_jobs * tiles_per_job;      // last workgroup only
+    if (AMVS_WG_SYNC_ROWS == 0 && idle_wave) return;
+    t = idle_wave ? 0 : t;
     const int job_id = t / tiles_per_job;
     const int rem = t - job_id * tiles_per_job;
     const int ty = rem / a.tiles_x;
@@ -335,7 +464,8 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     const int y0 = ty * a.TH;
     const int xr = xbase + lane;
     const bool col_in = (unsigned)xr < (unsigned)W;
-    const int rows = min(a.TH, H - y0) + 2 * HALF;
+    const int rows = idle_wave ? 0 : min(a.TH, H - y0) + 2 * HALF;
+    const int rows_wg = AMVS_WG_SYNC_ROWS ? a.TH + 2 * HALF : rows;
 
     float ring_r[K];
     float ring_v[Ring<S>::NR][K];
@@ -362,17 +492,49 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
     // still takes 82 % of its time -- the kernel is bound by instruction issue, not by memory.
     const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
     const int noff = oy * W + ox;
+#ifdef AMVS_TIMERS
+    Timers tm = {};
+    tm.last = __builtin_amdgcn_s_memtime();
+#endif
 
-    for (int r = 0; r < rows; ++r) {
+#ifdef AMVS_PREFETCH_ROW
+    float pf_d;
+    uint32_t pf_r;
+    {
+        const int yn = y0 - HALF;
+        const bool live_n = col_in & ((unsigned)yn < (unsigned)H);
+        const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
+        pf_d = d_in[inb_n ? yn * W + xr + noff : 0];
+        pf_r = U8 ? (uint32_t)ref_pairs[live_n ? yn * W + xr : 0] : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
+    }
+#endif
+    for (int r = 0; r < rows_wg; ++r) {
+        if (AMVS_WG_SYNC_ROWS && AMVS_WG_WAVES > 1) {
+            if (r % (AMVS_WG_SYNC_ROWS ? AMVS_WG_SYNC_ROWS : 1) == 0) __builtin_amdgcn_s_barrier();
+            if (r >= rows) continue;
+        }
         const int yr = y0 - HALF + r;
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
+#ifdef AMVS_PREFETCH_ROW
+        // depth and ref gray of the next row are requested a whole row ahead of their use
+        const float d_raw = pf_d;
+        const float r_raw = U8 ? lut[pf_r & 0xFFu] : __uint_as_float(pf_r);
+        {
+            const int yn = yr + 1;
+            const bool live_n = col_in & ((unsigned)yn < (unsigned)H) & (r + 1 < rows);
+            const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
+            pf_d = d_in[inb_n ? pix + W + noff : 0];
+            pf_r = U8 ? (uint32_t)ref_pairs[live_n ? pix + W : 0] : __float_as_uint(ref[live_n ? pix + W : 0]);
+        }
+#else
         const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
         const float r_raw = U8 ? lut[ref_pairs[AMVS_SIDX(live ? pix : 0)] & 0xFFu]
                                : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
+#endif
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
@@ -395,7 +557,8 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
         const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
 
         float v[S];
-        const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
+        AMVS_TMARK(0, true);
+        const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
 
         // ---- push into the vertical rings ----
         ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
@@ -404,6 +567,7 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
 #pragma unroll
         for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
         hist_h0[HALF] = h0;
+        AMVS_TMARK(3, false);
 
         if (r < 2 * HALF) continue;
 
@@ -445,26 +609,34 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
             total = (hit & (mode != MODE_CONF)) ? total + cost : total;
             cnt = hit ? cnt + 1.0f : cnt;
         }
+        AMVS_TMARK(4, true);
+        // lanes that own an output pixel; control flow below stays wave-uniform (the refinement
+        // queue needs every lane), so the stores are predicated instead of skipped
 #ifdef AMVS_ABL_NOSTORE
-        if (!(outl & (cnt > 1e30f))) continue;
+        const bool act = outl & (cnt > 1e30f);
 #else
-        if (!outl) continue;
+        const bool act = outl;
 #endif
 
-        if (mode == MODE_CONF) { aux[pc] = cnt; continue; }
+        if (mode == MODE_CONF) {
+            if (act) aux[pc] = cnt;
+            continue;
+        }
 
         // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
         const float cden = cnt + 1e-8f;
         const float avg = qdiv(total, cden, rcp_rn(cden));
         const float newc = cnt >= 2.0f ? avg : __builtin_inff();
-        if (mode == MODE_EVAL) { aux[pc] = newc; continue; }
+        if (mode == MODE_EVAL) {
+            if (act) aux[pc] = newc;
+            continue;
+        }
 
         // ---- select (mvs_patchmatch.py:452-455 / :486-489) ----
-        // HBM traffic is what bounds this kernel, so state is only moved where it
-        // has to be: depth goes to the other buffer for every pixel; cost is rewritten in place and
-        // only where the candidate wins; a refinement step reads and rewrites the normal in place and
-        // only where the candidate wins (4.5 % of the pixels on average).
-        const bool better = newc < oldc;
+        // State is only moved where it has to be: depth goes to the other buffer for every pixel;
+        // cost is rewritten in place and only where the candidate wins; a refinement step rewrites
+        // the normal in place and only where the candidate wins (4.5 % of the pixels on average).
+        const bool better = act & (newc < oldc);
         if (better) cost_io[pc] = newc;
         if (mode == MODE_PROP) {
             // candidate = the neighbour's pre-step state; out-of-image neighbour: depth_min and a
@@ -475,28 +647,51 @@ __global__ __launch_bounds__(AMVS_WAVE, min_waves(K, S)) void pm_step_kernel(con
             const float nb_d = d_in[pn];
             float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
             const bool zero = better & !inb_c;
-            AMVS_ST_STREAM(&d_out[pc], better ? (inb_c ? nb_d : a.depth_min) : oldd);
-            AMVS_ST_STREAM(&n_out[3 * pc], zero ? 0.0f : t0);
-            AMVS_ST_STREAM(&n_out[3 * pc + 1], zero ? 0.0f : t1);
-            AMVS_ST_STREAM(&n_out[3 * pc + 2], zero ? 0.0f : t2);
+            if (act) {
+                AMVS_ST_STREAM(&d_out[pc], better ? (inb_c ? nb_d : a.depth_min) : oldd);
+                AMVS_ST_STREAM(&n_out[3 * pc], zero ? 0.0f : t0);
+                AMVS_ST_STREAM(&n_out[3 * pc + 1], zero ? 0.0f : t1);
+                AMVS_ST_STREAM(&n_out[3 * pc + 2], zero ? 0.0f : t2);
+            }
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            AMVS_ST_STREAM(&d_out[pc], better ? d : oldd);
-            if (better) {
-                // normalize(normal + randn*range)   (mvs_patchmatch.py:475-476)
-                float g0, g1, g2;
-                rng_normals3(h0c, g0, g1, g2);
-                float cn0 = n_out[3 * pc] + g0 * a.normal_range;
-                float cn1 = n_out[3 * pc + 1] + g1 * a.normal_range;
-                float cn2 = n_out[3 * pc + 2] + g2 * a.normal_range;
-                normalize3(cn0, cn1, cn2);
-                n_out[3 * pc] = cn0; n_out[3 * pc + 1] = cn1; n_out[3 * pc + 2] = cn2;
+            if (act) AMVS_ST_STREAM(&d_out[pc], better ? d : oldd);
+#ifndef AMVS_ABL_NONORMAL
+            // The winners' normals (normalize(normal + randn*range), mvs_patchmatch.py:475-476) are
+            // not updated here: a row has ~3 winners among its 58 pixels, yet the ~150-instruction
+            // update would run for the whole wave on almost every row.  Winners are queued in LDS
+            // (pixel, hash) and updated 64 at a time -- same arithmetic, 1/20 of the issue slots.
+            // Nothing else reads or writes a pixel's normal during a refinement launch.
+            const unsigned long long won = __ballot(better);
+            if (won != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
+                q_tail += __popcll(won);
+                if (q_tail - q_head >= AMVS_WAVE) {
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
+                    q_head += AMVS_WAVE;
+                }
             }
+#endif
+        }
+        AMVS_TMARK(5, false);
+    }
+    if (mode == MODE_REFINE) {
+        while (q_tail - q_head > 0) {
+            const int n = min(q_tail - q_head, AMVS_WAVE);
+            refine_normals(nq, q_head, n, lane, n_out, a.normal_range);
+            q_head += n;
         }
     }
+#ifdef AMVS_TIMERS
+    if ((blockIdx.x % 4099) == 7 && lane == 0 && (a.draw % 10 == 1 || a.draw % 10 == 5))
+        printf("TM mode %d draw %u rows %d ph %llu %llu %llu %llu %llu %llu\n", mode, a.draw, rows, tm.acc[0], tm.acc[1],
+               tm.acc[2], tm.acc[3], tm.acc[4], tm.acc[5]);
+#endif
 }
 
 // ------------------------------------------------------------------ plane sweep --
@@ -560,6 +755,9 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
         }
         int wslot = 0;
+#ifdef AMVS_TIMERS
+        Timers tm = {};
+#endif
 
         for (int r = 0; r < rows; ++r) {
             const int yr = y0 - HALF + r;
@@ -570,7 +768,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             JobCP jr = reload(job);
             const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
             float v[S];
-            const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v);
+            const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
             ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
             wslot = wslot + 1 == K ? 0 : wslot + 1;
             hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
@@ -791,10 +989,11 @@ static unsigned dyn_lds_bytes()
 template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
+    const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     if (a.pairs)
-        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), dyn_lds_bytes(), st, a);
+        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nwg), dim3(AMVS_WAVE * AMVS_WG_WAVES), dyn_lds_bytes(), st, a);
     else
-        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), dyn_lds_bytes(), st, a);
+        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nwg), dim3(AMVS_WAVE * AMVS_WG_WAVES), dyn_lds_bytes(), st, a);
     return hipGetLastError();
 }
 template <int K, int S>
@@ -821,9 +1020,10 @@ template <int K, int S>
 static int step_occupancy_ks(bool u8)
 {
     int n = 0;
-    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true>, AMVS_WAVE, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false>, AMVS_WAVE, 0);
-    return e == hipSuccess && n > 0 ? n : 8;
+    constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
+    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true>, TPB, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false>, TPB, 0);
+    return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
 // resident single-wave blocks per CU of the sweep kernel (register-limited)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build an experimental libamvs variant for A/B runs:  tools/build_variant.sh NAME -DFOO=1 ...
+# -> build/variants/libamvs_NAME.so   (select it at run time with AMVS_LIB=<path>)
+set -e
+name=$1; shift
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/3d-reconstruction-tool_amd/csrc
+out=$root/build/variants; mkdir -p $out/obj_$name
+flags="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fvisibility=hidden -Wall -Wno-unused-result"
+for f in amvs_kernels amvs_capi amvs_fusion; do
+  if [ $f = amvs_kernels ] || [ ! -f $src/$f.o ]; then
+    /opt/rocm/bin/hipcc $flags "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
+  else
+    cp $src/$f.o $out/obj_$name/$f.o
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libamvs_$name.so $out/obj_$name/*.o
+rm -rf $out/obj_$name
+echo built $out/libamvs_$name.so
