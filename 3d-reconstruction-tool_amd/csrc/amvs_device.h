@@ -241,6 +241,7 @@ struct SampleConsts {
     float fw, fh;        // W-1, H-1
     float rfw, rfh;      // RN(1/(W-1)), RN(1/(H-1))
     float hw2, hh2;      // (W-1)/2, (H-1)/2
+    float fw1, fh1;      // W-2, H-2: largest x0 / y0 whose 2x2 footprint is inside the image
     float lo, hix, hiy;  // validity window of the projection
 };
 
@@ -256,6 +257,7 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
     c.fw = uniform_f(fw); c.fh = uniform_f(fh);
     c.rfw = uniform_f(1.0f / fw); c.rfh = uniform_f(1.0f / fh);
     c.hw2 = uniform_f(fw * 0.5f); c.hh2 = uniform_f(fh * 0.5f);
+    c.fw1 = uniform_f(fw - 1.0f); c.fh1 = uniform_f(fh - 1.0f);
     c.lo = lo; c.hix = hix; c.hiy = hiy;
     return c;
 }
@@ -283,6 +285,8 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
 template <bool U8> struct TapGeom;
 template <> struct TapGeom<true> {
     float nw, ne, sw, se;
+    bool fast;          // wave-uniform: every live lane's 2x2 footprint is inside the image, so the
+                        // read needs no clamp, the taps no masks and the byte positions are fixed
     int off;            // ushort index of the 4-byte read
     uint32_t sel;       // [4:0] left-column shift, [12:8] right-column shift, [20:16] bottom-row
                         // shift, [27:24] tap masks (t00,t01,t10,t11)
@@ -328,39 +332,71 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
     TapGeom<U8> g;
     g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
-    const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
-    const bool y0ok = (y0 >= 0.0f) & (y0 <= c.fh), y1ok = (y1 >= 0.0f) & (y1 <= c.fh);
-    uint32_t sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
-                   ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
     const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
+    uint32_t sel = 0u;
+    bool fast = false;
     if constexpr (U8) {
-        // clamped base keeps the 4-byte read inside the row; which bytes are the left / right
-        // column and the top / bottom row follows from where the clamp moved it
-        const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
-        g.off = live ? yb * W + xb : 0;
-        sel |= (x0i > xb ? 16u : 0u) | (x0i < xb ? 0u : 16u << 8) | (y0i < yb ? 0u : 8u << 16);
+#ifdef AMVS_INTERIOR_PATH
+        // Optional interior fast path (a wave-uniform branch): away from the image border every
+        // lane of a row usually lands inside the source, and the border bookkeeping of the other
+        // branch (8 compares, the tap masks, the clamps and the byte-position selects, ~35 VALU
+        // operations per source) is dead weight.  Same values either way (inside, every mask is
+        // true, the clamps are identities and the bytes sit at 0 / 8 / 16 / 24; parity tests pass),
+        // but the two code paths cost the k=7, S=4 kernel 21 more VGPRs (112: four waves per SIMD
+        // instead of five) and it measured 4 % slower on MI355X (33.1 vs 34.4 G px-hyp/s): off.
+        const bool inside = (x0 >= 0.0f) & (x0 <= c.fw1) & (y0 >= 0.0f) & (y0 <= c.fh1);
+        fast = __all(inside | !live);
+#endif
+        g.fast = fast;
+    }
+    if (fast) {
+        if constexpr (U8) g.off = live ? y0i * W + x0i : 0;
     } else {
-        const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
-        const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
-        g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
-        g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
+        const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
+        const bool y0ok = (y0 >= 0.0f) & (y0 <= c.fh), y1ok = (y1 >= 0.0f) & (y1 <= c.fh);
+        sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
+              ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
+        if constexpr (U8) {
+            // clamped base keeps the 4-byte read inside the row; which bytes are the left / right
+            // column and the top / bottom row follows from where the clamp moved it
+            const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
+            g.off = live ? yb * W + xb : 0;
+            sel |= (x0i > xb ? 16u : 0u) | (x0i < xb ? 0u : 16u << 8) | (y0i < yb ? 0u : 8u << 16);
+        } else {
+            const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
+            const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
+            g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
+            g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
+        }
     }
     g.sel = sel;
     return g;
 }
 
+// `img` is a device address from the job table: typed as a global pointer here, or the compiler
+// would have to emit FLAT loads (which also count on the LDS/scalar wait counter)
+typedef const __attribute__((address_space(1))) char *GlobalBytes;
+typedef const __attribute__((address_space(1))) float *GlobalFloats;
+
+AMVS_DEV uint32_t load_pair_word(unsigned long long img, int off)
+{
+    uint32_t w;
+    __builtin_memcpy(&w, (GlobalBytes)img + 2ll * off, 4);
+    return w;
+}
+
 template <bool U8>
-AMVS_DEV TapRaw<U8> sample_load(const void *__restrict__ img, const TapGeom<U8> &g)
+AMVS_DEV TapRaw<U8> sample_load(unsigned long long img, const TapGeom<U8> &g)
 {
     TapRaw<U8> r;
     if constexpr (U8) {
 #ifdef AMVS_ABLATE_L1_GATHER   // timing-only experiment: every gather hits a 2 KB window
-        __builtin_memcpy(&r.w, (const char *)img + 2 * (g.off & 1023), 4);
+        r.w = load_pair_word(img, g.off & 1023);
 #else
-        __builtin_memcpy(&r.w, (const char *)img + 2 * g.off, 4);
+        r.w = load_pair_word(img, g.off);
 #endif
     } else {
-        const float *__restrict__ f = (const float *)img;
+        const GlobalFloats f = (GlobalFloats)img;
         r.t00 = f[g.o00]; r.t01 = f[g.o01]; r.t10 = f[g.o10]; r.t11 = f[g.o11];
     }
     return r;
@@ -371,25 +407,28 @@ AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const fl
 {
     float t00, t01, t10, t11;
     if constexpr (U8) {
-        const uint32_t lsh = g.sel & 31u, rsh = (g.sel >> 8) & 31u, bsh = (g.sel >> 16) & 31u;
-#ifdef AMVS_ABL_NOLUT
-        t00 = (float)((r.w >> lsh) & 0xFFu) * 0.003921569f;
-        t10 = (float)((r.w >> (lsh + bsh)) & 0xFFu) * 0.003921569f;
-        t01 = (float)((r.w >> rsh) & 0xFFu) * 0.003921569f;
-        t11 = (float)((r.w >> (rsh + bsh)) & 0xFFu) * 0.003921569f;
-#else
-        t00 = lut[(r.w >> lsh) & 0xFFu];
-        t10 = lut[(r.w >> (lsh + bsh)) & 0xFFu];
-        t01 = lut[(r.w >> rsh) & 0xFFu];
-        t11 = lut[(r.w >> (rsh + bsh)) & 0xFFu];
-#endif
+        if (g.fast) {
+            t00 = lut[r.w & 0xFFu];
+            t10 = lut[(r.w >> 8) & 0xFFu];
+            t01 = lut[(r.w >> 16) & 0xFFu];
+            t11 = lut[r.w >> 24];
+        } else {
+            const uint32_t lsh = g.sel & 31u, rsh = (g.sel >> 8) & 31u, bsh = (g.sel >> 16) & 31u;
+            t00 = lut[(r.w >> lsh) & 0xFFu];
+            t10 = lut[(r.w >> (lsh + bsh)) & 0xFFu];
+            t01 = lut[(r.w >> rsh) & 0xFFu];
+            t11 = lut[(r.w >> (rsh + bsh)) & 0xFFu];
+            t00 = (g.sel & (1u << 24)) ? t00 : 0.0f;
+            t01 = (g.sel & (1u << 25)) ? t01 : 0.0f;
+            t10 = (g.sel & (1u << 26)) ? t10 : 0.0f;
+            t11 = (g.sel & (1u << 27)) ? t11 : 0.0f;
+        }
     } else {
-        t00 = r.t00; t01 = r.t01; t10 = r.t10; t11 = r.t11;
+        t00 = (g.sel & (1u << 24)) ? r.t00 : 0.0f;
+        t01 = (g.sel & (1u << 25)) ? r.t01 : 0.0f;
+        t10 = (g.sel & (1u << 26)) ? r.t10 : 0.0f;
+        t11 = (g.sel & (1u << 27)) ? r.t11 : 0.0f;
     }
-    t00 = (g.sel & (1u << 24)) ? t00 : 0.0f;
-    t01 = (g.sel & (1u << 25)) ? t01 : 0.0f;
-    t10 = (g.sel & (1u << 26)) ? t10 : 0.0f;
-    t11 = (g.sel & (1u << 27)) ? t11 : 0.0f;
     float v = __builtin_fmaf(t11, g.se, __builtin_fmaf(t10, g.sw, __builtin_fmaf(t01, g.ne, t00 * g.nw)));
     return live ? v : 0.0f;
 }

@@ -90,14 +90,19 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 #define AMVS_TM_ARG
 #endif
 
+// -DAMVS_NO_PAIRS=0 samples the sources two at a time with packed fp32 arithmetic (sample_geom_pair:
+// 5 % fewer VALU instructions, two gather waits per row instead of four, bit-identical results).
+// Measured on MI355X (16 views 1080p, k=7, S=4) it is 2 % SLOWER than the scalar path (33.5 vs 34.1
+// G px-hyp/s): packed operations want wait states after most producers and the interleaved pose
+// table costs more scalar loads, so the scalar path stays the default.
 #ifndef AMVS_NO_PAIRS
-#define AMVS_NO_PAIRS 0
+#define AMVS_NO_PAIRS 1
 #endif
 
-// Every scalar operand the sampling of one source (or source pair) needs, fetched as ONE batch of
-// scalar loads with a single wait: left to itself the compiler issues the pose, the intrinsics and
-// the image pointer in three separate load / wait rounds per source, and those serialised
-// scalar-cache latencies were ~10 % of the launch (timing ablation with immediates).
+// Every scalar operand the sampling of one source (or source pair) needs.  -DAMVS_SMEM_BATCH pins
+// them into ONE batch of scalar loads with a single wait (left to itself the compiler issues the
+// pose, the intrinsics and the image pointer in three load / wait rounds per source); measured 1 %
+// slower (more scalar registers live, more of them spilled to vector lanes), so it is off.
 struct SrcScalars { float K[6], R[9], t[3]; unsigned long long img; };
 AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 {
@@ -109,7 +114,7 @@ AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 #pragma unroll
     for (int i = 0; i < 3; ++i) c.t[i] = jr->ts[s][i];
     c.img = u8 ? jr->src_pairs[s] : jr->src_gray[s];
-#ifndef AMVS_NO_SMEM_BATCH
+#ifdef AMVS_SMEM_BATCH
     asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
                  "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
                  "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]), "+s"(c.img));
@@ -131,7 +136,7 @@ AMVS_DEV PairScalars load_pair_scalars(JobCP jr, int pr)
     for (int i = 0; i < 6; ++i) c.gc[i] = (v2f){jr->gridc[i][0], jr->gridc[i][1]};
     c.img[0] = jr->src_pairs[2 * pr];
     c.img[1] = jr->src_pairs[2 * pr + 1];
-#ifndef AMVS_NO_SMEM_BATCH
+#ifdef AMVS_SMEM_BATCH
     asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
                  "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
                  "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]),
@@ -164,8 +169,7 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
     jr = reload(jr);
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        const void *src = (const void *)(U8 ? jr->src_pairs[s] : jr->src_gray[s]);
-        tr[s] = sample_load<U8>(src, tg[s]);
+        tr[s] = sample_load<U8>(U8 ? jr->src_pairs[s] : jr->src_gray[s], tg[s]);
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
@@ -179,9 +183,8 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
             const PairScalars c = load_pair_scalars(jr, s / 2);
             const TapGeomPair tg = sample_geom_pair(c.K, c.R, c.t, c.gc, sc, Pw, live, ok0, ok1);
             okbits |= (ok0 ? (1u << s) : 0u) | (ok1 ? (2u << s) : 0u);
-            uint32_t w0, w1;
-            __builtin_memcpy(&w0, (const char *)c.img[0] + 2 * tg.off[0], 4);
-            __builtin_memcpy(&w1, (const char *)c.img[1] + 2 * tg.off[1], 4);
+            const uint32_t w0 = load_pair_word(c.img[0], tg.off[0]);
+            const uint32_t w1 = load_pair_word(c.img[1], tg.off[1]);
             AMVS_TMARK(1, false);
             AMVS_TMARK(2, true);
             const v2f vp = sample_finish_pair(w0, w1, tg, lut, live);
@@ -195,7 +198,7 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
         const SrcScalars c = load_src_scalars(jr, s, U8);
         const TapGeom<U8> tg = sample_geom<U8>(c.K, c.R, c.t, sc, Pw, live, ok);
         okbits |= ok ? (1u << s) : 0u;
-        const TapRaw<U8> tr = sample_load<U8>((const void *)c.img, tg);
+        const TapRaw<U8> tr = sample_load<U8>(c.img, tg);
         AMVS_TMARK(1, false);
         AMVS_TMARK(2, true);
         v[s] = sample_finish<U8>(tr, tg, lut, live);
