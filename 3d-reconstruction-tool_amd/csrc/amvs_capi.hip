@@ -166,6 +166,8 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
         std::memcpy(j.Rref, c->R[r].data(), 36);
         std::memcpy(j.tref, c->t[r].data(), 12);
         j.ref_img = r;
+        j.ref_pairs = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)r * c->pstride +
+                                                      amvs::pair_map_origin(c->W));
         j.stream_view = (uint32_t)r;
         j.slot = i;
         {
@@ -178,7 +180,8 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             if (v < 0 || v >= c->n_views || !c->have[v])
                 return fail(c, AMVS_EINVAL, "source view " + std::to_string(v) + " not uploaded");
             j.src_img[s] = v;
-            j.src_pairs[s] = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride);
+            j.src_pairs[s] = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride +
+                                                             amvs::pair_map_origin(c->W));
             j.src_gray[s] = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
             std::memcpy(j.Rs[s], c->R[v].data(), 36);
             std::memcpy(j.ts[s], c->t[v].data(), 12);
@@ -355,7 +358,7 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     std::memcpy(c->Kinv, K_inv, 36);
     c->R.resize(n_views); c->t.resize(n_views); c->have.assign(n_views, 0);
     c->exact8.assign(n_views, 0);
-    c->pstride = (((long long)H * W + 63) / 64) * 64 + 64;
+    c->pstride = ((amvs::pair_map_elems(H, W) + 63) / 64) * 64 + 64;
     {
         const char *e = std::getenv("AMVS_FORCE_F32_SAMPLING");
         c->force_f32 = e && e[0] == '1';

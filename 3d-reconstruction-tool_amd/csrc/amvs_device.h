@@ -241,7 +241,6 @@ struct SampleConsts {
     float fw, fh;        // W-1, H-1
     float rfw, rfh;      // RN(1/(W-1)), RN(1/(H-1))
     float hw2, hh2;      // (W-1)/2, (H-1)/2
-    float fw1, fh1;      // W-2, H-2: largest x0 / y0 whose 2x2 footprint is inside the image
     float lo, hix, hiy;  // validity window of the projection
 };
 
@@ -257,7 +256,6 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
     c.fw = uniform_f(fw); c.fh = uniform_f(fh);
     c.rfw = uniform_f(1.0f / fw); c.rfh = uniform_f(1.0f / fh);
     c.hw2 = uniform_f(fw * 0.5f); c.hh2 = uniform_f(fh * 0.5f);
-    c.fw1 = uniform_f(fw - 1.0f); c.fh1 = uniform_f(fh - 1.0f);
     c.lo = lo; c.hix = hix; c.hiy = hiy;
     return c;
 }
@@ -276,20 +274,21 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
 // sample is 0 (the zero padding of the box filter).
 //
 // U8 = false: the source is the float32 gray map; four dword gathers over two image rows.
-// U8 = true : the source is the packed 8-bit row-pair map (ushort (y,x) = code(y,x) |
-//             code(y+1,x) << 8) of an image whose every pixel equals code/255 exactly (what
-//             cvtColor(...).astype(float32)/255 produces, mvs_patchmatch.py:177).  One
-//             2-byte-aligned dword gather fetches the whole 2x2 footprint; codes are decoded
-//             through the 256-entry table `lut` in LDS (lut[c] = (float)c / 255.0f), so the tap
-//             values are bit-identical to the float32 map's.
+// U8 = true : the source is the packed 8-bit row-pair map of an image whose every pixel equals
+//             code/255 exactly (what cvtColor(...).astype(float32)/255 produces,
+//             mvs_patchmatch.py:177): ushort (y,x) = code(y,x) | code(y+1,x) << 8, stored with a
+//             TWO-texel border of zero codes on every side (row pitch W+4; code = 0 outside the
+//             image).  One 2-byte-aligned dword gather fetches the whole 2x2 footprint with the
+//             bytes at fixed positions, and the zero border IS grid_sample's zero padding: the
+//             footprint origin is clamped to [-2, W] x [-2, H], where a tap outside the image reads
+//             code 0 -> 0.0f, exactly what the reference's masked tap contributes -- no tap masks,
+//             no byte-position selects.  Codes are decoded through the 256-entry table `lut` in
+//             LDS (lut[c] = (float)c / 255.0f), so tap values are bit-identical to the float32 map's.
+#define AMVS_PAIR_BORDER 2
 template <bool U8> struct TapGeom;
 template <> struct TapGeom<true> {
     float nw, ne, sw, se;
-    bool fast;          // wave-uniform: every live lane's 2x2 footprint is inside the image, so the
-                        // read needs no clamp, the taps no masks and the byte positions are fixed
-    int off;            // ushort index of the 4-byte read
-    uint32_t sel;       // [4:0] left-column shift, [12:8] right-column shift, [20:16] bottom-row
-                        // shift, [27:24] tap masks (t00,t01,t10,t11)
+    int off;            // ushort index of the 4-byte read, relative to image pixel (0,0) of the padded map
 };
 template <> struct TapGeom<false> {
     float nw, ne, sw, se;
@@ -333,43 +332,21 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     TapGeom<U8> g;
     g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
     const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
-    uint32_t sel = 0u;
-    bool fast = false;
     if constexpr (U8) {
-#ifdef AMVS_INTERIOR_PATH
-        // Optional interior fast path (a wave-uniform branch): away from the image border every
-        // lane of a row usually lands inside the source, and the border bookkeeping of the other
-        // branch (8 compares, the tap masks, the clamps and the byte-position selects, ~35 VALU
-        // operations per source) is dead weight.  Same values either way (inside, every mask is
-        // true, the clamps are identities and the bytes sit at 0 / 8 / 16 / 24; parity tests pass),
-        // but the two code paths cost the k=7, S=4 kernel 21 more VGPRs (112: four waves per SIMD
-        // instead of five) and it measured 4 % slower on MI355X (33.1 vs 34.4 G px-hyp/s): off.
-        const bool inside = (x0 >= 0.0f) & (x0 <= c.fw1) & (y0 >= 0.0f) & (y0 <= c.fh1);
-        fast = __all(inside | !live);
-#endif
-        g.fast = fast;
-    }
-    if (fast) {
-        if constexpr (U8) g.off = live ? y0i * W + x0i : 0;
+        // footprint origin clamped into the zero border (a NaN / infinite coordinate has NaN
+        // weights, so which texels it reads does not matter)
+        const int cx = min(max(x0i, -AMVS_PAIR_BORDER), W), cy = min(max(y0i, -AMVS_PAIR_BORDER), H);
+        g.off = live ? cy * (W + 2 * AMVS_PAIR_BORDER) + cx : 0;
     } else {
         const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
         const bool y0ok = (y0 >= 0.0f) & (y0 <= c.fh), y1ok = (y1 >= 0.0f) & (y1 <= c.fh);
-        sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
-              ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
-        if constexpr (U8) {
-            // clamped base keeps the 4-byte read inside the row; which bytes are the left / right
-            // column and the top / bottom row follows from where the clamp moved it
-            const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
-            g.off = live ? yb * W + xb : 0;
-            sel |= (x0i > xb ? 16u : 0u) | (x0i < xb ? 0u : 16u << 8) | (y0i < yb ? 0u : 8u << 16);
-        } else {
-            const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
-            const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
-            g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
-            g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
-        }
+        g.sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
+                ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
+        const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
+        const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
+        g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
+        g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
     }
-    g.sel = sel;
     return g;
 }
 
@@ -407,22 +384,10 @@ AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const fl
 {
     float t00, t01, t10, t11;
     if constexpr (U8) {
-        if (g.fast) {
-            t00 = lut[r.w & 0xFFu];
-            t10 = lut[(r.w >> 8) & 0xFFu];
-            t01 = lut[(r.w >> 16) & 0xFFu];
-            t11 = lut[r.w >> 24];
-        } else {
-            const uint32_t lsh = g.sel & 31u, rsh = (g.sel >> 8) & 31u, bsh = (g.sel >> 16) & 31u;
-            t00 = lut[(r.w >> lsh) & 0xFFu];
-            t10 = lut[(r.w >> (lsh + bsh)) & 0xFFu];
-            t01 = lut[(r.w >> rsh) & 0xFFu];
-            t11 = lut[(r.w >> (rsh + bsh)) & 0xFFu];
-            t00 = (g.sel & (1u << 24)) ? t00 : 0.0f;
-            t01 = (g.sel & (1u << 25)) ? t01 : 0.0f;
-            t10 = (g.sel & (1u << 26)) ? t10 : 0.0f;
-            t11 = (g.sel & (1u << 27)) ? t11 : 0.0f;
-        }
+        t00 = lut[r.w & 0xFFu];
+        t10 = lut[(r.w >> 8) & 0xFFu];
+        t01 = lut[(r.w >> 16) & 0xFFu];
+        t11 = lut[r.w >> 24];
     } else {
         t00 = (g.sel & (1u << 24)) ? r.t00 : 0.0f;
         t01 = (g.sel & (1u << 25)) ? r.t01 : 0.0f;
@@ -439,7 +404,6 @@ AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const fl
 struct TapGeomPair {
     v2f nw, ne, sw, se;
     int off[2];
-    uint32_t sel[2];
 };
 
 template <class KP, class RPP, class TPP, class GPP>
@@ -449,7 +413,6 @@ AMVS_DEV TapGeomPair sample_geom_pair(KP K, RPP RsP, TPP tsP, GPP gc, const Samp
     const int H = c.H, W = c.W;
     // gc: W-1, H-1, their reciprocals and halves, each as a scalar-register pair
 #define AMVS_GC(i) (gc[i])
-    const float cfw = gc[0].x, cfh = gc[1].x;
     const v2f X = splat2(Pw.x), Y = splat2(Pw.y), Z = splat2(Pw.z);
 #define AMVS_PR(i) (RsP[i])
 #define AMVS_PT(i) (tsP[i])
@@ -478,38 +441,19 @@ AMVS_DEV TapGeomPair sample_geom_pair(KP K, RPP RsP, TPP tsP, GPP gc, const Samp
     g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const float fx0 = h ? x0.y : x0.x, fy0 = h ? y0.y : y0.x, fx1 = h ? x1.y : x1.x, fy1 = h ? y1.y : y1.x;
-        const bool x0ok = (fx0 >= 0.0f) & (fx0 <= cfw), x1ok = (fx1 >= 0.0f) & (fx1 <= cfw);
-        const bool y0ok = (fy0 >= 0.0f) & (fy0 <= cfh), y1ok = (fy1 >= 0.0f) & (fy1 <= cfh);
-        uint32_t sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
-                       ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
-        const int x0i = (int)fx0, y0i = (int)fy0;
-        const int xb = min(max(x0i, 0), W - 2), yb = min(max(y0i, 0), H - 1);
-        g.off[h] = live ? yb * W + xb : 0;
-        sel |= (x0i > xb ? 16u : 0u) | (x0i < xb ? 0u : 16u << 8) | (y0i < yb ? 0u : 8u << 16);
-        g.sel[h] = sel;
+        const int x0i = (int)(h ? x0.y : x0.x), y0i = (int)(h ? y0.y : y0.x);
+        const int cx = min(max(x0i, -AMVS_PAIR_BORDER), W), cy = min(max(y0i, -AMVS_PAIR_BORDER), H);
+        g.off[h] = live ? cy * (W + 2 * AMVS_PAIR_BORDER) + cx : 0;
     }
     return g;
 }
 
 AMVS_DEV v2f sample_finish_pair(uint32_t w0, uint32_t w1, const TapGeomPair &g, const float *lut, bool live)
 {
-    v2f t00, t01, t10, t11;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t w = h ? w1 : w0, sel = g.sel[h];
-        const uint32_t lsh = sel & 31u, rsh = (sel >> 8) & 31u, bsh = (sel >> 16) & 31u;
-        float a00 = lut[(w >> lsh) & 0xFFu];
-        float a10 = lut[(w >> (lsh + bsh)) & 0xFFu];
-        float a01 = lut[(w >> rsh) & 0xFFu];
-        float a11 = lut[(w >> (rsh + bsh)) & 0xFFu];
-        a00 = (sel & (1u << 24)) ? a00 : 0.0f;
-        a01 = (sel & (1u << 25)) ? a01 : 0.0f;
-        a10 = (sel & (1u << 26)) ? a10 : 0.0f;
-        a11 = (sel & (1u << 27)) ? a11 : 0.0f;
-        if (h) { t00.y = a00; t01.y = a01; t10.y = a10; t11.y = a11; }
-        else   { t00.x = a00; t01.x = a01; t10.x = a10; t11.x = a11; }
-    }
+    const v2f t00 = {lut[w0 & 0xFFu], lut[w1 & 0xFFu]};
+    const v2f t10 = {lut[(w0 >> 8) & 0xFFu], lut[(w1 >> 8) & 0xFFu]};
+    const v2f t01 = {lut[(w0 >> 16) & 0xFFu], lut[(w1 >> 16) & 0xFFu]};
+    const v2f t11 = {lut[w0 >> 24], lut[w1 >> 24]};
     v2f v = fma2(t11, g.se, fma2(t10, g.sw, fma2(t01, g.ne, t00 * g.nw)));
     v.x = live ? v.x : 0.0f;
     v.y = live ? v.y : 0.0f;

@@ -24,7 +24,9 @@ struct Job {
     int src_img[AMVS_KMAX_SRC];
     // device addresses of the source maps (packed 8-bit row pairs / float32 gray), so that the
     // kernels do not rebuild base + index * stride on the scalar unit for every source and row
+    // (packed maps: address of image pixel (0,0) inside the zero-bordered map)
     unsigned long long src_pairs[AMVS_KMAX_SRC], src_gray[AMVS_KMAX_SRC];
+    unsigned long long ref_pairs;
     uint32_t stream_view;   // RNG stream id (the reference view's index)
     int slot;               // state / output slot inside the batch buffers
 };
@@ -78,6 +80,8 @@ hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st);
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
                             int first_img, int n_img, float *mean_out, float *var_out,
                             hipStream_t st);
+long long pair_map_elems(int H, int W);      // ushorts of one zero-bordered packed map
+long long pair_map_origin(int W);            // ushort offset of image pixel (0,0) inside it
 hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, int *inexact,
                              hipStream_t st);
 hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,

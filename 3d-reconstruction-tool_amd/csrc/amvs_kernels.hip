@@ -447,7 +447,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     const long long HW = (long long)H * W;
 
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
-    const uint16_t *__restrict__ ref_pairs = a.pairs + (U8 ? job->ref_img * a.pair_stride : 0);
+    // ref gray of the packed path: low byte of the padded row-pair map (pitch W+4, origin at pixel (0,0))
+    const uint16_t *__restrict__ ref_pairs = U8 ? (const uint16_t *)job->ref_pairs : a.pairs;
+    constexpr int PADW = U8 ? 2 * AMVS_PAIR_BORDER : 0;
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
     const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const bool live_n = col_in & ((unsigned)yn < (unsigned)H);
         const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         pf_d = d_in[inb_n ? yn * W + xr + noff : 0];
-        pf_r = U8 ? (uint32_t)ref_pairs[live_n ? yn * W + xr : 0] : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
+        pf_r = U8 ? (uint32_t)ref_pairs[live_n ? yn * (W + PADW) + xr : 0] : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
     }
 #endif
     for (int r = 0; r < rows_wg; ++r) {
@@ -529,13 +531,13 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             const bool live_n = col_in & ((unsigned)yn < (unsigned)H) & (r + 1 < rows);
             const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
             pf_d = d_in[inb_n ? pix + W + noff : 0];
-            pf_r = U8 ? (uint32_t)ref_pairs[live_n ? pix + W : 0] : __float_as_uint(ref[live_n ? pix + W : 0]);
+            pf_r = U8 ? (uint32_t)ref_pairs[live_n ? pix + W + PADW * (yr + 1) : 0] : __float_as_uint(ref[live_n ? pix + W : 0]);
         }
 #else
         const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
-        const float r_raw = U8 ? lut[ref_pairs[AMVS_SIDX(live ? pix : 0)] & 0xFFu]
+        const float r_raw = U8 ? lut[ref_pairs[AMVS_SIDX(live ? pix + PADW * yr : 0)] & 0xFFu]
                                : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
 #endif
 
@@ -882,22 +884,28 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------ 8-bit pack ---
-// Build the packed row-pair map of one view and test that it is lossless: pixel (y,x) gets
-// code = rint(g*255) clamped to [0,255]; `inexact` is raised if any pixel differs from
-// (float)code / 255.0f, in which case the sweep keeps sampling the float32 map.
+// Build the packed row-pair map of one view (layout: amvs_device.h, "U8 = true") and test that it
+// is lossless: pixel (y,x) gets code = rint(g*255) clamped to [0,255]; `inexact` is raised if any
+// pixel differs from (float)code / 255.0f, in which case the sweep keeps sampling the float32 map.
+// `pairs` is the padded map's first element; entry (y,x), y in [-2, H+2), x in [-2, W+2), is
+// code(y,x) | code(y+1,x) << 8 with code = 0 outside the image.
 __global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict__ img, int H, int W,
                                                          uint16_t *__restrict__ pairs,
                                                          int *__restrict__ inexact)
 {
-    const long long n = (long long)H * W;
+    constexpr int B = AMVS_PAIR_BORDER;
+    const int PW = W + 2 * B;
+    const long long n = (long long)(H + 2 * B) * PW;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(i / W);
-        const float g0 = img[i];
-        const float g1 = y + 1 < H ? img[i + W] : g0;
+        const int y = (int)(i / PW) - B, x = (int)(i % PW) - B;
+        const bool xin = (unsigned)x < (unsigned)W;
+        const bool in0 = xin & ((unsigned)y < (unsigned)H), in1 = xin & ((unsigned)(y + 1) < (unsigned)H);
+        const float g0 = in0 ? img[(long long)y * W + x] : 0.0f;
+        const float g1 = in1 ? img[(long long)(y + 1) * W + x] : 0.0f;
         const int c0 = min(max((int)__builtin_rintf(g0 * 255.0f), 0), 255);
         const int c1 = min(max((int)__builtin_rintf(g1 * 255.0f), 0), 255);
-        if (!((float)c0 / 255.0f == g0)) atomicOr(inexact, 1);
+        if (in0 & !((float)c0 / 255.0f == g0)) atomicOr(inexact, 1);
         pairs[i] = (uint16_t)(c0 | (c1 << 8));
     }
 }
@@ -905,11 +913,19 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict
 hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, int *inexact,
                              hipStream_t st)
 {
-    const long long n = (long long)H * W;
+    const long long n = (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER);
     const int bx = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_pairs_kernel, dim3(bx), dim3(256), 0, st, img, H, W, pairs, inexact);
     return hipGetLastError();
 }
+
+// ushorts one padded map occupies (before alignment)
+long long pair_map_elems(int H, int W)
+{
+    return (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER);
+}
+// ushort offset of image pixel (0,0) inside a padded map
+long long pair_map_origin(int W) { return (long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER; }
 
 // ------------------------------------------------------------------ init ---------
 // depth = exp(rand*(ln dmax - ln dmin) + ln dmin); normal = normalize(randn*0.3,
