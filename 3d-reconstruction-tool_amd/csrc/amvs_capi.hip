@@ -180,8 +180,7 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             if (v < 0 || v >= c->n_views || !c->have[v])
                 return fail(c, AMVS_EINVAL, "source view " + std::to_string(v) + " not uploaded");
             j.src_img[s] = v;
-            j.src_pairs[s] = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride +
-                                                             amvs::pair_map_origin(c->W));
+            j.src_pairs[s] = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride);
             j.src_gray[s] = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
             std::memcpy(j.Rs[s], c->R[v].data(), 36);
             std::memcpy(j.ts[s], c->t[v].data(), 12);
@@ -346,6 +345,7 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     if (H < 2 || W < 2 || n_views < 1 || !K || !K_inv)
         return fail(nullptr, AMVS_EINVAL, "bad image size / view count / intrinsics");
     if ((long long)H * W > (1ll << 29)) return fail(nullptr, AMVS_EINVAL, "image too large (H*W must stay below 2^29: 32-bit pixel indices, 3 per normal)");
+    if (H > (1 << 23) || W > (1 << 23)) return fail(nullptr, AMVS_EINVAL, "image side above 2^23 (24-bit row arithmetic)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, AMVS_EHIP, "no HIP device available (this backend has no CPU fallback)");

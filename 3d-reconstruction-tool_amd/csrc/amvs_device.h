@@ -288,7 +288,7 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
 template <bool U8> struct TapGeom;
 template <> struct TapGeom<true> {
     float nw, ne, sw, se;
-    int off;            // ushort index of the 4-byte read, relative to image pixel (0,0) of the padded map
+    int off;            // ushort index of the 4-byte read from the first element of the padded map (>= 0)
 };
 template <> struct TapGeom<false> {
     float nw, ne, sw, se;
@@ -331,13 +331,19 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
     TapGeom<U8> g;
     g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
-    const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
     if constexpr (U8) {
         // footprint origin clamped into the zero border (a NaN / infinite coordinate has NaN
         // weights, so which texels it reads does not matter)
-        const int cx = min(max(x0i, -AMVS_PAIR_BORDER), W), cy = min(max(y0i, -AMVS_PAIR_BORDER), H);
-        g.off = live ? cy * (W + 2 * AMVS_PAIR_BORDER) + cx : 0;
+        // (clamped as floats: one v_med3_f32 each, which also maps a NaN to the lower bound)
+        const int cx = (int)__builtin_amdgcn_fmed3f(x0, -(float)AMVS_PAIR_BORDER, c.fw + 1.0f);
+        const int cy = (int)__builtin_amdgcn_fmed3f(y0, -(float)AMVS_PAIR_BORDER, c.fh + 1.0f);
+        // unsigned ushort index from the first element of the padded map (<= 2^29 + small)
+        // (24-bit multiply: rows and pitch are far below 2^24; the full 32-bit one is a 64-bit mad)
+        const unsigned idx = __umul24((unsigned)(cy + AMVS_PAIR_BORDER), (unsigned)(W + 2 * AMVS_PAIR_BORDER)) +
+                             (unsigned)(cx + AMVS_PAIR_BORDER);
+        g.off = live ? (int)idx : 0;
     } else {
+        const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
         const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
         const bool y0ok = (y0 >= 0.0f) & (y0 <= c.fh), y1ok = (y1 >= 0.0f) & (y1 <= c.fh);
         g.sel = ((x0ok & y0ok) ? 1u << 24 : 0u) | ((x1ok & y0ok) ? 1u << 25 : 0u) |
@@ -355,10 +361,12 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
 typedef const __attribute__((address_space(1))) char *GlobalBytes;
 typedef const __attribute__((address_space(1))) float *GlobalFloats;
 
+// 4 bytes at ushort index `off` (non-negative) of the padded map starting at `img`: uniform 64-bit
+// base + 32-bit byte offset, i.e. the scalar-base form of global_load
 AMVS_DEV uint32_t load_pair_word(unsigned long long img, int off)
 {
     uint32_t w;
-    __builtin_memcpy(&w, (GlobalBytes)img + 2ll * off, 4);
+    __builtin_memcpy(&w, (GlobalBytes)img + (unsigned long long)(2u * (unsigned)off), 4);
     return w;
 }
 
@@ -410,7 +418,7 @@ template <class KP, class RPP, class TPP, class GPP>
 AMVS_DEV TapGeomPair sample_geom_pair(KP K, RPP RsP, TPP tsP, GPP gc, const SampleConsts &c, Vec3 Pw, bool live,
                                       bool &valid0, bool &valid1)
 {
-    const int H = c.H, W = c.W;
+    const int W = c.W;
     // gc: W-1, H-1, their reciprocals and halves, each as a scalar-register pair
 #define AMVS_GC(i) (gc[i])
     const v2f X = splat2(Pw.x), Y = splat2(Pw.y), Z = splat2(Pw.z);
@@ -441,9 +449,11 @@ AMVS_DEV TapGeomPair sample_geom_pair(KP K, RPP RsP, TPP tsP, GPP gc, const Samp
     g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int x0i = (int)(h ? x0.y : x0.x), y0i = (int)(h ? y0.y : y0.x);
-        const int cx = min(max(x0i, -AMVS_PAIR_BORDER), W), cy = min(max(y0i, -AMVS_PAIR_BORDER), H);
-        g.off[h] = live ? cy * (W + 2 * AMVS_PAIR_BORDER) + cx : 0;
+        const int cx = (int)__builtin_amdgcn_fmed3f(h ? x0.y : x0.x, -(float)AMVS_PAIR_BORDER, gc[0].x + 1.0f);
+        const int cy = (int)__builtin_amdgcn_fmed3f(h ? y0.y : y0.x, -(float)AMVS_PAIR_BORDER, gc[1].x + 1.0f);
+        const unsigned idx = __umul24((unsigned)(cy + AMVS_PAIR_BORDER), (unsigned)(W + 2 * AMVS_PAIR_BORDER)) +
+                             (unsigned)(cx + AMVS_PAIR_BORDER);
+        g.off[h] = live ? (int)idx : 0;
     }
     return g;
 }

@@ -24,7 +24,7 @@ struct Job {
     int src_img[AMVS_KMAX_SRC];
     // device addresses of the source maps (packed 8-bit row pairs / float32 gray), so that the
     // kernels do not rebuild base + index * stride on the scalar unit for every source and row
-    // (packed maps: address of image pixel (0,0) inside the zero-bordered map)
+    // (src_pairs: first element of the zero-bordered map; ref_pairs: its image pixel (0,0))
     unsigned long long src_pairs[AMVS_KMAX_SRC], src_gray[AMVS_KMAX_SRC];
     unsigned long long ref_pairs;
     uint32_t stream_view;   // RNG stream id (the reference view's index)
