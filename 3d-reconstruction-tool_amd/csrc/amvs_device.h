@@ -48,6 +48,47 @@ AMVS_DEV float sqrt_rn(float x)
     return g;
 }
 
+// Optimistic forms for the hot loops: the lean result is always computed and the validity of the
+// operand is ANDed into `ok` instead of branching; the caller tests `ok` once per stage and row
+// (one wave-uniform branch instead of one per call) and, when some lane saw an operand outside the
+// verified range, repeats the stage with LEAN = false (plain IEEE operations).  The stages are
+// pure functions of their inputs, so the repeat is safe; it is practically never taken.
+AMVS_DEV bool lean_exp_ok(float x) { return (((__float_as_uint(x) >> 23) & 0xFFu) - 32u) <= 190u; }
+
+template <bool LEAN>
+AMVS_DEV float rcp_t(float x, bool &ok)
+{
+    if constexpr (LEAN) {
+        float r = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(r, e, r);
+        ok &= lean_exp_ok(x);
+        return r;
+    } else {
+        return 1.0f / x;
+    }
+}
+
+template <bool LEAN>
+AMVS_DEV float sqrt_t(float x, bool &ok)
+{
+    if constexpr (LEAN) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y;
+        float h = 0.5f * y;
+        const float r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g);
+        h = __builtin_fmaf(h, r, h);
+        const float d = __builtin_fmaf(-g, g, x);
+        g = __builtin_fmaf(d, h, g);
+        g = x == 0.0f ? x : g;
+        ok &= lean_exp_ok(x) | (x == 0.0f);
+        return g;
+    } else {
+        return __builtin_sqrtf(x);
+    }
+}
+
 // ---------------------------------------------------------------- RNG ------
 // Counter-hash generator standing in for torch.rand / torch.randn
 // (mvs_patchmatch.py:271,279,280,471,475).  A "draw" gives every pixel one
@@ -183,8 +224,6 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 AMVS_DEV v2f splat2(float x) { return (v2f){x, x}; }
 AMVS_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-AMVS_DEV bool lean_exp_ok(float x) { return (((__float_as_uint(x) >> 23) & 0xFFu) - 32u) <= 190u; }
-
 AMVS_DEV v2f rcp_rn2(v2f x)
 {
     v2f r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
@@ -299,8 +338,9 @@ template <bool U8> struct TapRaw;
 template <> struct TapRaw<true> { uint32_t w; };
 template <> struct TapRaw<false> { float t00, t01, t10, t11; };
 
-template <bool U8, class KP, class RP, class TP>
-AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3 Pw, bool live, bool &valid)
+template <bool U8, bool LEAN, class KP, class RP, class TP>
+AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3 Pw, bool live, bool &valid,
+                                 bool &ok)
 {
     const int H = c.H, W = c.W;
 #ifdef AMVS_ABL_NOPROJ      // timing-only: no projection arithmetic
@@ -311,7 +351,7 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
     float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
     float zz = z + 1e-8f;
-    float rz = rcp_rn(zz);
+    float rz = rcp_t<LEAN>(zz, ok);
     float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];

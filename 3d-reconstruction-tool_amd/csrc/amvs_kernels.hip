@@ -99,6 +99,15 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 #define AMVS_NO_PAIRS 1
 #endif
 
+// Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
+// (1) or after every operation / source (0).  The plane sweep always uses the per-row form (+3 %).
+#ifndef AMVS_PM_ROW_CHECK_SAMPLING
+#define AMVS_PM_ROW_CHECK_SAMPLING 0
+#endif
+#ifndef AMVS_PM_ROW_CHECK_NCC
+#define AMVS_PM_ROW_CHECK_NCC 0
+#endif
+
 // Every scalar operand the sampling of one source (or source pair) needs.  -DAMVS_SMEM_BATCH pins
 // them into ONE batch of scalar loads with a single wait (left to itself the compiler issues the
 // pose, the intrinsics and the image pointer in three load / wait rounds per source); measured 1 %
@@ -146,34 +155,18 @@ AMVS_DEV PairScalars load_pair_scalars(JobCP jr, int pr)
     return c;
 }
 
-// Sample all S sources of one pixel.  AMVS_PHASED: geometry of every source, then all gathers,
-// then decode (gathers issue back to back); default: source by source.  Same arithmetic either
-// way.  Measured on MI355X (16 views 1080p, k=7, S=4): source-by-source 26.9, phased 22.7 (128
-// VGPR) / 25.2 (147 VGPR) G px-hyp/s.
-template <int S, bool U8>
+// Sample all S sources of one pixel, source by source.  (Issuing the geometry of every source
+// first and the S gathers back to back was measured slower on MI355X -- 22.7 / 25.2 G px-hyp/s at
+// 128 / 147 VGPRs vs 26.9 -- and is no longer carried in the source.)
+// LEAN / `ok`: optimistic lean reciprocal (amvs_device.h).  SRC_CHECK = true tests `ok` after each
+// source's geometry and repeats that geometry with IEEE arithmetic (one wave-uniform branch per
+// source); SRC_CHECK = false leaves the test to the caller (one branch per row).
+template <int S, bool U8, bool LEAN, bool SRC_CHECK>
 AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                 Vec3 Pw, bool live, float (&v)[S] AMVS_TM_PARAM)
+                                 Vec3 Pw, bool live, float (&v)[S], bool &ok AMVS_TM_PARAM)
 {
     unsigned okbits = 0u;
     JobCP jr = job;
-#ifdef AMVS_PHASED
-    TapGeom<U8> tg[S];
-    TapRaw<U8> tr[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        bool ok;
-        jr = reload(jr);
-        tg[s] = sample_geom<U8>(jr->K, jr->Rs[s], jr->ts[s], sc, Pw, live, ok);
-        okbits |= ok ? (1u << s) : 0u;
-    }
-    jr = reload(jr);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        tr[s] = sample_load<U8>(U8 ? jr->src_pairs[s] : jr->src_gray[s], tg[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
-#else
     constexpr int SP = (U8 && !AMVS_NO_PAIRS) ? (S & ~1) : 0;     // sources handled as pairs
     if constexpr (U8) {
 #pragma unroll
@@ -193,17 +186,37 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
     }
 #pragma unroll
     for (int s = SP; s < S; ++s) {
-        bool ok;
+        bool valid;
         jr = AMVS_SRC_RELOAD(jr);
         const SrcScalars c = load_src_scalars(jr, s, U8);
-        const TapGeom<U8> tg = sample_geom<U8>(c.K, c.R, c.t, sc, Pw, live, ok);
-        okbits |= ok ? (1u << s) : 0u;
+        TapGeom<U8> tg;
+        if constexpr (SRC_CHECK) {
+            bool ok_s = true;
+            tg = sample_geom<U8, true>(c.K, c.R, c.t, sc, Pw, live, valid, ok_s);
+            if (__builtin_expect(!__all(ok_s), 0)) tg = sample_geom<U8, false>(c.K, c.R, c.t, sc, Pw, live, valid, ok_s);
+        } else {
+            tg = sample_geom<U8, LEAN>(c.K, c.R, c.t, sc, Pw, live, valid, ok);
+        }
+        okbits |= valid ? (1u << s) : 0u;
         const TapRaw<U8> tr = sample_load<U8>(c.img, tg);
         AMVS_TMARK(1, false);
         AMVS_TMARK(2, true);
         v[s] = sample_finish<U8>(tr, tg, lut, live);
     }
-#endif
+    return okbits;
+}
+
+// Optimistic sampling of a row: lean arithmetic first; the IEEE repeat only when some lane's
+// projection depth left the range the lean reciprocal is verified for (amvs_device.h).
+template <int S, bool U8, bool ROW_CHECK>
+AMVS_DEV unsigned sample_sources_checked(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
+                                         Vec3 Pw, bool live, float (&v)[S] AMVS_TM_PARAM)
+{
+    bool ok = true;
+    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true>(job, a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
+    unsigned okbits = sample_sources<S, U8, true, false>(job, a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
+    if (__builtin_expect(!__all(ok), 0))
+        okbits = sample_sources<S, U8, false, false>(reload(job), a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
     return okbits;
 }
 
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 
         float v[S];
         AMVS_TMARK(0, true);
-        const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
+        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
 
         // ---- push into the vertical rings ----
         ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
@@ -591,6 +604,42 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const float m1 = br * INV_AREA;
         const float v1 = brr * INV_AREA - m1 * m1;
 
+#if AMVS_PM_ROW_CHECK_NCC
+        // NCC of every source + aggregation; optimistic lean sqrt / reciprocal with one check per
+        // row (amvs_device.h), IEEE repeat if a window's variance product left the verified range
+        float total, cnt;
+        auto ncc_stage = [&](auto lean, bool &ok) {
+            constexpr bool LEAN = decltype(lean)::value;
+            total = 0.0f; cnt = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
+                // _ncc_cost (mvs_patchmatch.py:403-411)
+                const float mean2 = bv * INV_AREA;
+                const float var2 = bvv * INV_AREA - mean2 * mean2;
+                const float cov = brv * INV_AREA - m1 * mean2;
+#ifdef AMVS_ABL_NONCC        // timing-only: no sqrt / divide
+                const float cost = cov + v1 * var2;
+#else
+                const float den = sqrt_t<LEAN>(v1 * var2, ok) + 1e-8f;
+                const float ncc = qdiv(cov, den, rcp_t<LEAN>(den, ok));
+                const float cost = 1.0f - ncc;
+#endif
+                const bool oks = (okc >> s) & 1u;
+                // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
+                const float ncc2 = 1.0f - cost;
+                const bool hit = mode == MODE_CONF ? (oks & (ncc2 > 0.6f)) : oks;
+                // cost: total += where(valid, cost, 0); count += valid   (:383-384)
+                total = (hit & (mode != MODE_CONF)) ? total + cost : total;
+                cnt = hit ? cnt + 1.0f : cnt;
+            }
+        };
+        {
+            bool ok = true;
+            ncc_stage(std::true_type{}, ok);
+            if (__builtin_expect(!__all(ok), 0)) ncc_stage(std::false_type{}, ok);
+        }
+#else
         float total = 0.0f, cnt = 0.0f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -599,13 +648,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             const float mean2 = bv * INV_AREA;
             const float var2 = bvv * INV_AREA - mean2 * mean2;
             const float cov = brv * INV_AREA - m1 * mean2;
-#ifdef AMVS_ABL_NONCC        // timing-only: no sqrt / divide
-            const float cost = cov + v1 * var2;
-#else
             const float den = sqrt_rn(v1 * var2) + 1e-8f;
             const float ncc = qdiv(cov, den, rcp_rn(den));
             const float cost = 1.0f - ncc;
-#endif
             const bool oks = (okc >> s) & 1u;
             // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
             const float ncc2 = 1.0f - cost;
@@ -614,6 +659,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             total = (hit & (mode != MODE_CONF)) ? total + cost : total;
             cnt = hit ? cnt + 1.0f : cnt;
         }
+#endif
         AMVS_TMARK(4, true);
         // lanes that own an output pixel; control flow below stays wave-uniform (the refinement
         // queue needs every lane), so the stores are predicated instead of skipped
@@ -629,8 +675,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         }
 
         // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
-        const float cden = cnt + 1e-8f;
-        const float avg = qdiv(total, cden, rcp_rn(cden));
+        const float cden = cnt + 1e-8f;              // 1e-8 ... S: always inside the lean reciprocal's range
+        bool cden_ok = true;
+        const float avg = qdiv(total, cden, rcp_t<true>(cden, cden_ok));
         const float newc = cnt >= 2.0f ? avg : __builtin_inff();
         if (mode == MODE_EVAL) {
             if (act) aux[pc] = newc;
@@ -773,7 +820,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             JobCP jr = reload(job);
             const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
             float v[S];
-            const unsigned okbits = sample_sources<S, U8>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
+            const unsigned okbits = sample_sources_checked<S, U8, true>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
             ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
             wslot = wslot + 1 == K ? 0 : wslot + 1;
             hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
@@ -788,16 +835,25 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const float m1 = br * INV_AREA;
             const float v1 = brr * INV_AREA - m1 * m1;
             uint32_t votes = 0u;
+            auto vote_stage = [&](auto lean, bool &ok) {
+                constexpr bool LEAN = decltype(lean)::value;
+                votes = 0u;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
-                // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
-                const float mean2 = bv * INV_AREA;
-                const float var2 = bvv * INV_AREA - mean2 * mean2;
-                const float cov = brv * INV_AREA - m1 * mean2;
-                const float den = sqrt_rn(v1 * var2 + 1e-8f);
-                const float ncc = qdiv(cov, den, rcp_rn(den));
-                if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+                for (int s = 0; s < S; ++s) {
+                    const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
+                    // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
+                    const float mean2 = bv * INV_AREA;
+                    const float var2 = bvv * INV_AREA - mean2 * mean2;
+                    const float cov = brv * INV_AREA - m1 * mean2;
+                    const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
+                    const float ncc = qdiv(cov, den, rcp_t<LEAN>(den, ok));
+                    if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+                }
+            };
+            {
+                bool ok = true;
+                vote_stage(std::true_type{}, ok);
+                if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
             }
             if (outl) {
                 const uint32_t keyv = (votes << 16) | (uint32_t)(65535 - d);
