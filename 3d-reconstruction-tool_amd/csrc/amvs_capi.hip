@@ -651,7 +651,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.n_jobs = n_ref; a.D = D;
     {
         const long long strips = (long long)n_ref * a.tiles_x * a.tiles_y;
-        const long long slots = (long long)c->n_cu * 16;
+        const long long slots = (long long)c->n_cu * 16;        // four waves per SIMD
         long long want = (4 * slots + strips - 1) / strips;      // chunks for ~4 waves per slot
         if (want < 1) want = 1;
         if (want > D) want = D;
@@ -660,6 +660,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
             const int v = std::atoi(e);
             if (v >= 1) a.chunk = v < D ? v : D;
         }
+        if (a.chunk > AMVS_SWEEP_MAX_CHUNK) a.chunk = AMVS_SWEEP_MAX_CHUNK;
         a.n_chunks = (D + a.chunk - 1) / a.chunk;
     }
     c->last_tile_rows = a.TH;

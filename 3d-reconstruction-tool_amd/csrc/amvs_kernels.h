@@ -5,6 +5,7 @@
 
 #define AMVS_KMAX_SRC 6
 #define AMVS_SWEEP_MAX_TH 32
+#define AMVS_SWEEP_MAX_CHUNK 4096     // planes one wave sweeps (12-bit plane index in its LDS keys)
 
 namespace amvs {
 

@@ -749,16 +749,18 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 // ------------------------------------------------------------------ plane sweep --
 // _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
 // count neighbours with NCC > thresh and z > 0.1; keep the first plane with the highest
-// count.  A wave keeps the running best of its strip in LDS ((count<<16)|(65535-plane),
-// so a plain max implements torch.max's first-index rule) and never materialises the
-// (D,H,W) volume the reference allocates (:262).
+// count.  A wave keeps the running best of its strip and plane chunk in LDS as a 16-bit key
+// ((count << 12) | (4095 - plane index inside the chunk): a plain max implements torch.max's
+// first-index rule; 16 bits keep the strip's keys at 4 KB, which is what lets four waves per SIMD
+// fit the 160 KB of LDS) and never materialises the (D,H,W) volume the reference allocates (:262).
+// Chunks are merged through atomicMax on the 32-bit key (count << 16) | (65535 - plane).
 template <int K, int S, bool U8>
 __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs a)
 {
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
-    __shared__ uint32_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
+    __shared__ uint16_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
     __shared__ float lut[256];
     #ifdef AMVS_HSUM_LDS
     __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     const int trows = min(a.TH, H - y0);
     const int rows = trows + 2 * HALF;
 
-    for (int i = 0; i < trows; ++i) best[i][lane] = 0u;
+    for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
 
     for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[d];
@@ -856,11 +858,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
                 if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
             }
             if (outl) {
-                const uint32_t keyv = (votes << 16) | (uint32_t)(65535 - d);
+                const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
                 const uint32_t cur = best[yc - y0][lane];
-                // plane 0 always enters (torch.max over a volume that starts at 0 votes): its key
-                // (0<<16)|65535 beats the initial 0
-                if (keyv > cur) best[yc - y0][lane] = keyv;
+                // the chunk's first plane always enters (torch.max over a volume that starts at 0
+                // votes): its key (0 << 12) | 4095 beats the initial 0
+                if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
             }
         }
     }
@@ -868,7 +870,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     unsigned *__restrict__ keys = a.keys + job->slot * HW;
     const int xc = xr + HALF;
     if (lane < OUTW && xc < W)
-        for (int i = 0; i < trows; ++i) atomicMax(&keys[(y0 + i) * W + xc], best[i][lane]);
+        for (int i = 0; i < trows; ++i) {
+            const uint32_t b = best[i][lane];
+            const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
+            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
+        }
 }
 
 // decode the merged keys: depth of the winning plane (dense_stereo.py:310) and its vote count
