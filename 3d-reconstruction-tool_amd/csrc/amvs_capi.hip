@@ -170,6 +170,7 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
                                                       amvs::pair_map_origin(c->W));
         j.stream_view = (uint32_t)r;
         j.slot = i;
+        j.n_src = n_src;
         {
             const float fw = (float)(c->W - 1), fh = (float)(c->H - 1);
             const float gc[6] = {fw, fh, 1.0f / fw, 1.0f / fh, fw * 0.5f, fh * 0.5f};
@@ -179,11 +180,10 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             const int v = src_ids[i * n_src + s];
             if (v < 0 || v >= c->n_views || !c->have[v])
                 return fail(c, AMVS_EINVAL, "source view " + std::to_string(v) + " not uploaded");
-            j.src_img[s] = v;
-            j.src_pairs[s] = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride);
-            j.src_gray[s] = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
-            std::memcpy(j.Rs[s], c->R[v].data(), 36);
-            std::memcpy(j.ts[s], c->t[v].data(), 12);
+            j.src[s].pairs = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)v * c->pstride);
+            j.src[s].gray = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
+            std::memcpy(j.src[s].R, c->R[v].data(), 36);
+            std::memcpy(j.src[s].t, c->t[v].data(), 12);
             for (int e = 0; e < 9; ++e) j.RsP[s / 2][e][s & 1] = c->R[v][e];
             for (int e = 0; e < 3; ++e) j.tsP[s / 2][e][s & 1] = c->t[v][e];
         }

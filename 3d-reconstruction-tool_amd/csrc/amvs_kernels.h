@@ -9,27 +9,31 @@
 
 namespace amvs {
 
+// One source view of a job: everything its sampling needs in one 64-byte record (a single
+// s_load_dwordx16 and one wait per source instead of three load / wait rounds).
+struct alignas(64) SrcEntry {
+    float R[9], t[3];
+    unsigned long long pairs;   // first element of the zero-bordered packed map
+    unsigned long long gray;    // float32 gray map
+};
+
 // One reference view of a batch: its pose, its source views and where its state lives.
-struct Job {
+struct alignas(64) Job {
     float K[9], Kinv[9];    // shared intrinsics, copied per job so that the kernels fetch them with
                             // the same in-loop scalar loads as the poses
     float Rref[9], tref[3];
-    float Rs[AMVS_KMAX_SRC][9], ts[AMVS_KMAX_SRC][3];
+    int ref_img;
+    uint32_t stream_view;   // RNG stream id (the reference view's index)
+    int slot;               // state / output slot inside the batch buffers
+    int n_src;
+    unsigned long long ref_pairs;   // image pixel (0,0) of the reference view's packed map
+    SrcEntry src[AMVS_KMAX_SRC];
     // the same poses, two sources interleaved ([pair][entry][2]): one 64-bit scalar operand per
-    // matrix entry for the packed-fp32 projection of a source pair
+    // matrix entry for the packed-fp32 projection of a source pair (-DAMVS_NO_PAIRS=0)
     float RsP[AMVS_KMAX_SRC / 2][9][2], tsP[AMVS_KMAX_SRC / 2][3][2];
     // sampler constants, each duplicated into a pair for the same reason:
     // W-1, H-1, RN(1/(W-1)), RN(1/(H-1)), (W-1)/2, (H-1)/2
     float gridc[6][2];
-    int ref_img;
-    int src_img[AMVS_KMAX_SRC];
-    // device addresses of the source maps (packed 8-bit row pairs / float32 gray), so that the
-    // kernels do not rebuild base + index * stride on the scalar unit for every source and row
-    // (src_pairs: first element of the zero-bordered map; ref_pairs: its image pixel (0,0))
-    unsigned long long src_pairs[AMVS_KMAX_SRC], src_gray[AMVS_KMAX_SRC];
-    unsigned long long ref_pairs;
-    uint32_t stream_view;   // RNG stream id (the reference view's index)
-    int slot;               // state / output slot inside the batch buffers
 };
 
 enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };

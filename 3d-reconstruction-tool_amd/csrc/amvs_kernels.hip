@@ -108,24 +108,20 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 #define AMVS_PM_ROW_CHECK_NCC 0
 #endif
 
-// Every scalar operand the sampling of one source (or source pair) needs.  -DAMVS_SMEM_BATCH pins
-// them into ONE batch of scalar loads with a single wait (left to itself the compiler issues the
-// pose, the intrinsics and the image pointer in three load / wait rounds per source); measured 1 %
-// slower (more scalar registers live, more of them spilled to vector lanes), so it is off.
-struct SrcScalars { float K[6], R[9], t[3]; unsigned long long img; };
+// The scalar operands of one source: one 64-byte record of the job table (SrcEntry), i.e. one
+// s_load_dwordx16 and one wait.  (-DAMVS_SMEM_BATCH additionally pins them as a batch; the
+// compiler already keeps them together.)
+struct SrcScalars { float R[9], t[3]; unsigned long long img; };
 AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 {
     SrcScalars c;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c.K[i] = jr->K[i];
+    for (int i = 0; i < 9; ++i) c.R[i] = jr->src[s].R[i];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = jr->Rs[s][i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c.t[i] = jr->ts[s][i];
-    c.img = u8 ? jr->src_pairs[s] : jr->src_gray[s];
+    for (int i = 0; i < 3; ++i) c.t[i] = jr->src[s].t[i];
+    c.img = u8 ? jr->src[s].pairs : jr->src[s].gray;
 #ifdef AMVS_SMEM_BATCH
-    asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
-                 "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
+    asm volatile("" : "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
                  "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]), "+s"(c.img));
 #endif
     return c;
@@ -143,8 +139,8 @@ AMVS_DEV PairScalars load_pair_scalars(JobCP jr, int pr)
     for (int i = 0; i < 3; ++i) c.t[i] = (v2f){jr->tsP[pr][i][0], jr->tsP[pr][i][1]};
 #pragma unroll
     for (int i = 0; i < 6; ++i) c.gc[i] = (v2f){jr->gridc[i][0], jr->gridc[i][1]};
-    c.img[0] = jr->src_pairs[2 * pr];
-    c.img[1] = jr->src_pairs[2 * pr + 1];
+    c.img[0] = jr->src[2 * pr].pairs;
+    c.img[1] = jr->src[2 * pr + 1].pairs;
 #ifdef AMVS_SMEM_BATCH
     asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
                  "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
@@ -167,6 +163,10 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
 {
     unsigned okbits = 0u;
     JobCP jr = job;
+    // the shared intrinsics: loaded once per row, with the reference pose (same scalar-load batch)
+    float Kc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Kc[i] = jr->K[i];
     constexpr int SP = (U8 && !AMVS_NO_PAIRS) ? (S & ~1) : 0;     // sources handled as pairs
     if constexpr (U8) {
 #pragma unroll
@@ -184,25 +184,38 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
             v[s] = vp.x; v[s + 1] = vp.y;
         }
     }
+    // Geometry of every source first, each gather issued as soon as its address exists, then the
+    // decodes: the S gather latencies overlap (one exposed wait per row instead of S).  The taps'
+    // weights wait in registers meanwhile (5 per source) -- affordable since the window-sum stage,
+    // not the sampling stage, sets this kernel's register peak.
+    TapGeom<U8> tg[S];
+    TapRaw<U8> tr[S];
 #pragma unroll
     for (int s = SP; s < S; ++s) {
         bool valid;
         jr = AMVS_SRC_RELOAD(jr);
         const SrcScalars c = load_src_scalars(jr, s, U8);
-        TapGeom<U8> tg;
         if constexpr (SRC_CHECK) {
             bool ok_s = true;
-            tg = sample_geom<U8, true>(c.K, c.R, c.t, sc, Pw, live, valid, ok_s);
-            if (__builtin_expect(!__all(ok_s), 0)) tg = sample_geom<U8, false>(c.K, c.R, c.t, sc, Pw, live, valid, ok_s);
+            tg[s] = sample_geom<U8, true>(Kc, c.R, c.t, sc, Pw, live, valid, ok_s);
+            if (__builtin_expect(!__all(ok_s), 0)) tg[s] = sample_geom<U8, false>(Kc, c.R, c.t, sc, Pw, live, valid, ok_s);
         } else {
-            tg = sample_geom<U8, LEAN>(c.K, c.R, c.t, sc, Pw, live, valid, ok);
+            tg[s] = sample_geom<U8, LEAN>(Kc, c.R, c.t, sc, Pw, live, valid, ok);
         }
         okbits |= valid ? (1u << s) : 0u;
-        const TapRaw<U8> tr = sample_load<U8>(c.img, tg);
+        tr[s] = sample_load<U8>(c.img, tg[s]);
+#ifdef AMVS_GATHER_SERIAL    // previous structure: decode each source right after its gather
         AMVS_TMARK(1, false);
         AMVS_TMARK(2, true);
-        v[s] = sample_finish<U8>(tr, tg, lut, live);
+        v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
+#endif
     }
+#ifndef AMVS_GATHER_SERIAL
+    AMVS_TMARK(1, false);
+#pragma unroll
+    for (int s = SP; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
+    AMVS_TMARK(2, false);
+#endif
     return okbits;
 }
 
