@@ -101,6 +101,9 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 
 // Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
 // (1) or after every operation / source (0).  The plane sweep always uses the per-row form (+3 %).
+#ifndef AMVS_RELOAD_STRIDE
+#define AMVS_RELOAD_STRIDE 1
+#endif
 #ifndef AMVS_PM_ROW_CHECK_SAMPLING
 #define AMVS_PM_ROW_CHECK_SAMPLING 0
 #endif
@@ -193,7 +196,9 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
 #pragma unroll
     for (int s = SP; s < S; ++s) {
         bool valid;
-        jr = AMVS_SRC_RELOAD(jr);
+        // (the opaque pointer copy that keeps the scalar loads inside the loop is also a scheduling
+        // barrier: AMVS_RELOAD_STRIDE sources share one, so their arithmetic can interleave)
+        if ((s - SP) % AMVS_RELOAD_STRIDE == 0) jr = AMVS_SRC_RELOAD(jr);
         const SrcScalars c = load_src_scalars(jr, s, U8);
         if constexpr (SRC_CHECK) {
             bool ok_s = true;
