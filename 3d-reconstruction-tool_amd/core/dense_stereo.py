@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .camera import Camera, CameraPose
-from .imageprep import prepare_view
+from .imageprep import prepare_views
 from .. import engine as _engine
 from .. import parallel as _parallel
 
@@ -98,7 +98,7 @@ class DenseStereoReconstructor:
 
     # ------------------------------------------------------------------ host ------
     def _prepare_images(self, images: List[dict], indices: List[int]) -> Dict:
-        return {idx: prepare_view(images[idx]["image"], self.scale) for idx in indices}
+        return dict(zip(indices, prepare_views([images[idx]["image"] for idx in indices], self.scale)))
 
     def _find_neighbors(self, ref_idx: int, all_indices: List[int],
                         poses: Dict[int, CameraPose], k: int = 6) -> List[int]:

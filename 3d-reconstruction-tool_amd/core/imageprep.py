@@ -46,10 +46,13 @@ def _resize_linear_u8(img, new_w, new_h):
 
 def _bgr_to_gray_u8(img):
     """cv.cvtColor(BGR2GRAY) for 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14."""
-    b = img[:, :, 0].astype(np.int64)
-    g = img[:, :, 1].astype(np.int64)
-    r = img[:, :, 2].astype(np.int64)
-    return ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    # (32-bit arithmetic: the sum is below 2^22)
+    acc = img[:, :, 0].astype(np.uint32) * np.uint32(1868)
+    acc += img[:, :, 1].astype(np.uint32) * np.uint32(9617)
+    acc += img[:, :, 2].astype(np.uint32) * np.uint32(4899)
+    acc += np.uint32(8192)
+    acc >>= np.uint32(14)
+    return acc.astype(np.uint8)
 
 
 def prepare_view(image_bgr_u8: np.ndarray, scale: float) -> dict:
@@ -62,5 +65,16 @@ def prepare_view(image_bgr_u8: np.ndarray, scale: float) -> dict:
     else:
         scaled = _resize_linear_u8(np.ascontiguousarray(image_bgr_u8), new_w, new_h)
         gray8 = _bgr_to_gray_u8(scaled)
-    gray = gray8.astype(np.float32) / 255.0
+    gray = gray8.astype(np.float32)
+    gray /= np.float32(255.0)
     return {"color": scaled, "gray": gray, "shape": (new_h, new_w)}
+
+
+def prepare_views(images_bgr_u8, scale: float, workers: int = 8) -> list:
+    """prepare_view for a list of images on a small thread pool (the NumPy / OpenCV kernels
+    release the GIL); results in input order."""
+    if len(images_bgr_u8) <= 1 or workers <= 1:
+        return [prepare_view(im, scale) for im in images_bgr_u8]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(workers, len(images_bgr_u8))) as pool:
+        return list(pool.map(lambda im: prepare_view(im, scale), images_bgr_u8))

@@ -14,7 +14,10 @@ Differences a caller can observe, all opt-in or performance-only:
     (the reference re-uploads per view and loops serially, :104-123, :235-257);
   * `seed` names the RNG streams (the reference is unseeded);
   * under an initialised torch.distributed process group the reference views are
-    sharded over ranks and the per-view maps are all-gathered (see ..parallel).
+    sharded over ranks and the per-view maps are all-gathered (see ..parallel);
+  * with `device_fusion` (default) and torch-ROCm present the per-view maps never leave
+    the GPU: the sweep writes them into device tensors, the all-gather (RCCL) and the
+    fusion + filter read them there, and only the final cloud is copied to the host.
 """
 import time
 from dataclasses import dataclass
@@ -23,7 +26,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .camera import Camera, CameraPose
-from .imageprep import prepare_view
+from .imageprep import prepare_view, prepare_views
 from .. import engine as _engine
 from .. import parallel as _parallel
 
@@ -34,6 +37,31 @@ class DepthNormalMap:
     depth: np.ndarray       # (H, W) float32
     normal: np.ndarray      # (H, W, 3) float32
     confidence: np.ndarray  # (H, W) float32, number of photo-consistent source views
+
+
+@dataclass
+class _ResidentMaps:
+    """Maps of all swept views kept on the GPU (torch tensors), rows in job order."""
+    ref_ids: list            # reference view index per row
+    depth: object            # (n, H*W) float32
+    normal: object           # (n, H*W*3) float32
+    confidence: object       # (n, H*W) float32
+    shape: tuple
+
+    def to_host(self):
+        H, W = self.shape
+        d, n, c = self.depth.cpu().numpy(), self.normal.cpu().numpy(), self.confidence.cpu().numpy()
+        return {r: DepthNormalMap(depth=d[i].reshape(H, W), normal=n[i].reshape(H, W, 3),
+                                  confidence=c[i].reshape(H, W)) for i, r in enumerate(self.ref_ids)}
+
+
+def _torch_cuda():
+    """torch with a usable HIP device, or None (then maps travel through host arrays)."""
+    try:
+        import torch
+    except Exception:  # noqa: BLE001
+        return None
+    return torch if torch.cuda.is_available() else None
 
 
 class PatchMatchMVS:
@@ -94,6 +122,17 @@ class PatchMatchMVS:
                 continue
             jobs.append((ref_idx, src))
 
+        torch = _torch_cuda() if self.device_fusion else None
+        if torch is not None and jobs:
+            resident = self._sweep_resident(torch, jobs, proc_images, poses, cam_indices)
+            print("\nFusing depth maps...")
+            points, colors, raw = self._fuse_filter_resident(resident, proc_images, poses)
+            print(f"  Raw points: {raw:,}")
+            if raw > 0:
+                print(f"  After filtering: {len(points):,}")
+            print(f"\nPatchMatch MVS completed in {time.time() - t0:.1f}s")
+            return points, colors
+
         depth_maps = self._sweep(jobs, proc_images, poses, cam_indices)
 
         print("\nFusing depth maps...")
@@ -135,7 +174,8 @@ class PatchMatchMVS:
     def _prepare_images(self, images: List[dict], indices: List[int]) -> Dict:
         """Scaled colour + float32 gray in [0,1] per view (reference :167-191; the Sobel
         gradients computed there are never read and are not produced here)."""
-        return {idx: prepare_view(images[idx]["image"], self.scale) for idx in indices}
+        prepared = prepare_views([images[idx]["image"] for idx in indices], self.scale)
+        return dict(zip(indices, prepared))
 
     def _select_source_views(self, ref_idx: int, all_indices: List[int],
                              poses: Dict[int, CameraPose], k: int = 4) -> List[int]:
@@ -224,7 +264,79 @@ class PatchMatchMVS:
                                              self.process_group, DepthNormalMap)
         return {jobs[j][0]: local[j] for j in sorted(local)}
 
+    def _sweep_resident(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
+        """_sweep with the maps kept in device tensors: this rank's views are swept straight into
+        them (amvs_patchmatch_device), the all-gather runs on them (RCCL) and the valid-pixel
+        counts of the progress lines are reduced on the GPU."""
+        n_cams = len(cam_indices)
+        rank, world = _parallel.rank_world(self.process_group)
+        mine = _parallel.shard(len(jobs), rank, world)
+        eng = self._ensure_engine(proc_images, poses, cam_indices)
+        H, W = proc_images[cam_indices[0]]["shape"]
+        hw = H * W
+        dev = torch.device("cuda", self.device_id)
+        depth = torch.empty((len(mine), hw), dtype=torch.float32, device=dev)
+        normal = torch.empty((len(mine), 3 * hw), dtype=torch.float32, device=dev)
+        conf = torch.empty((len(mine), hw), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        row = {j: n for n, j in enumerate(mine)}
+        by_count = {}
+        for j in mine:
+            by_count.setdefault(len(jobs[j][1]), []).append(j)
+        # a batch writes its views to consecutive rows, so the batches are runs of consecutive jobs
+        for _, idxs in sorted(by_count.items()):
+            runs, cur = [], []
+            for j in idxs:
+                if cur and (j != cur[-1] + 1 or len(cur) == self.views_per_batch):
+                    runs.append(cur)
+                    cur = []
+                cur.append(j)
+            if cur:
+                runs.append(cur)
+            for chunk in runs:
+                t1 = time.time()
+                r0 = row[chunk[0]]
+                refs = [self._slot[jobs[j][0]] for j in chunk]
+                srcs = [[self._slot[s] for s in jobs[j][1]] for j in chunk]
+                eng.patchmatch_device(refs, srcs, self._pm_params(), self.seed_for_stream(),
+                                      depth[r0].data_ptr(), normal[r0].data_ptr(), conf[r0].data_ptr())
+                eng.sync()
+                self.last_timing = eng.timing()
+                per_view = (time.time() - t1) / len(chunk)
+                valid = (conf[r0:r0 + len(chunk)] >= self.min_views).sum(dim=1).tolist()
+                for n, j in enumerate(chunk):
+                    ref_idx = jobs[j][0]
+                    print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: "
+                          f"{int(valid[n]):,} valid pixels ({per_view:.1f}s)")
+        if world > 1:
+            # RCCL gathers the device tensors in place; any other backend (gloo in the tests)
+            # stages through the host
+            direct = torch.distributed.get_backend(self.process_group) == "nccl"
+
+            def gather(t, width):
+                full = _parallel.allgather_packed(t if direct else t.cpu(), len(jobs), width, self.process_group)
+                return full if direct else full.to(dev)
+            depth, normal, conf = gather(depth, hw), gather(normal, 3 * hw), gather(conf, hw)
+            order = list(range(len(jobs)))
+        else:
+            order = mine
+        return _ResidentMaps(ref_ids=[jobs[j][0] for j in order], depth=depth, normal=normal,
+                             confidence=conf, shape=(H, W))
+
     # ------------------------------------------------------------ fusion / filter --
+    def _fuse_filter_resident(self, maps: "_ResidentMaps", images: Dict, poses: Dict[int, CameraPose]):
+        """Fusion + filter straight from the device tensors of _sweep_resident."""
+        import torch
+        n = len(maps.ref_ids)
+        if n == 0:
+            return np.array([]).reshape(0, 3), np.array([]).reshape(0, 3), 0
+        cols = np.stack([images[i]["color"] for i in maps.ref_ids])
+        K_inv = np.linalg.inv(self.K_scaled)
+        torch.cuda.synchronize(maps.depth.device)
+        return self._engine.fuse_filter(None, None, cols, K_inv, [(poses[i].R, poses[i].t) for i in maps.ref_ids],
+                                        self.min_views, do_filter=True,
+                                        device_ptrs=(maps.depth.data_ptr(), maps.confidence.data_ptr(), n))
+
     def _fuse_filter_device(self, depth_maps: Dict[int, "DepthNormalMap"], images: Dict,
                             poses: Dict[int, CameraPose]):
         """_fuse_depth_maps + _filter_points on the GPU (amvs_fuse_filter): float64, same order,

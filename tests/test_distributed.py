@@ -46,6 +46,7 @@ def _reconstruct(scene, world_tag, use_engine=False):
         backend = _oracle_backend(scene, 7, 1, 2, 5)
         pm._ensure_engine = lambda images, poses, indices: setattr(pm, "_slot", {i: i for i in indices})
         pm._run_batch = lambda eng, batch: backend(batch)
+        pm.device_fusion = False        # host maps + NumPy fusion (bit-identical to the device path)
     # keep the synthetic scene's depth range (the reference would estimate it from sparse points)
     pm._estimate_depth_range = lambda poses, sparse: None
     pm.depth_min, pm.depth_max = scene.depth_min, scene.depth_max
