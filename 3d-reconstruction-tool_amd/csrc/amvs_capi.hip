@@ -166,8 +166,8 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
         std::memcpy(j.Rref, c->R[r].data(), 36);
         std::memcpy(j.tref, c->t[r].data(), 12);
         j.ref_img = r;
-        j.ref_pairs = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)r * c->pstride +
-                                                      amvs::pair_map_origin(c->W));
+        j.ref_pairs = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)r * c->pstride) +
+                      (unsigned long long)(amvs::pair_map_origin(c->W) * amvs::pair_map_texel_bytes());
         j.stream_view = (uint32_t)r;
         j.slot = i;
         j.n_src = n_src;

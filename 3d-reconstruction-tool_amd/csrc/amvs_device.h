@@ -324,6 +324,12 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
 //             no byte-position selects.  Codes are decoded through the 256-entry table `lut` in
 //             LDS (lut[c] = (float)c / 255.0f), so tap values are bit-identical to the float32 map's.
 #define AMVS_PAIR_BORDER 2
+// AMVS_CODE_BYTES = 1: the map holds ONE byte per texel (code(y,x), same zero border, row pitch W+4
+// bytes) and a footprint is two 2-byte gathers (rows y0 and y0+1) instead of one 4-byte gather of
+// a row pair: half the cache footprint per source image for one more load instruction.
+#ifndef AMVS_CODE_BYTES
+#define AMVS_CODE_BYTES 0
+#endif
 template <bool U8> struct TapGeom;
 template <> struct TapGeom<true> {
     float nw, ne, sw, se;
@@ -401,24 +407,37 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
 typedef const __attribute__((address_space(1))) char *GlobalBytes;
 typedef const __attribute__((address_space(1))) float *GlobalFloats;
 
-// 4 bytes at ushort index `off` (non-negative) of the padded map starting at `img`: uniform 64-bit
-// base + 32-bit byte offset, i.e. the scalar-base form of global_load
-AMVS_DEV uint32_t load_pair_word(unsigned long long img, int off)
+// The four codes of a footprint whose origin is texel index `off` (non-negative) of the padded map
+// starting at `img`: uniform 64-bit base + 32-bit byte offset, i.e. the scalar-base form of
+// global_load.  Row-pair layout: one dword, bytes (y,x) (y+1,x) (y,x+1) (y+1,x+1); byte layout: two
+// ushorts `pitch` bytes apart, combined to (y,x) (y,x+1) (y+1,x) (y+1,x+1).
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+AMVS_DEV uint32_t load_pair_word(unsigned long long img, int off, int pitch)
 {
+#if AMVS_CODE_BYTES
+    us2_t w;
+    unsigned short lo, hi;
+    __builtin_memcpy(&lo, (GlobalBytes)img + (unsigned long long)(unsigned)off, 2);
+    __builtin_memcpy(&hi, (GlobalBytes)img + (unsigned long long)(unsigned)(off + pitch), 2);
+    w.x = lo; w.y = hi;
+    return __builtin_bit_cast(uint32_t, w);
+#else
+    (void)pitch;
     uint32_t w;
     __builtin_memcpy(&w, (GlobalBytes)img + (unsigned long long)(2u * (unsigned)off), 4);
     return w;
+#endif
 }
 
 template <bool U8>
-AMVS_DEV TapRaw<U8> sample_load(unsigned long long img, const TapGeom<U8> &g)
+AMVS_DEV TapRaw<U8> sample_load(unsigned long long img, const TapGeom<U8> &g, int pitch)
 {
     TapRaw<U8> r;
     if constexpr (U8) {
 #ifdef AMVS_ABLATE_L1_GATHER   // timing-only experiment: every gather hits a 2 KB window
-        r.w = load_pair_word(img, g.off & 1023);
+        r.w = load_pair_word(img, g.off & 1023, pitch);
 #else
-        r.w = load_pair_word(img, g.off);
+        r.w = load_pair_word(img, g.off, pitch);
 #endif
     } else {
         const GlobalFloats f = (GlobalFloats)img;
@@ -432,10 +451,17 @@ AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const fl
 {
     float t00, t01, t10, t11;
     if constexpr (U8) {
+#if AMVS_CODE_BYTES
+        t00 = lut[r.w & 0xFFu];
+        t01 = lut[(r.w >> 8) & 0xFFu];
+        t10 = lut[(r.w >> 16) & 0xFFu];
+        t11 = lut[r.w >> 24];
+#else
         t00 = lut[r.w & 0xFFu];
         t10 = lut[(r.w >> 8) & 0xFFu];
         t01 = lut[(r.w >> 16) & 0xFFu];
         t11 = lut[r.w >> 24];
+#endif
     } else {
         t00 = (g.sel & (1u << 24)) ? r.t00 : 0.0f;
         t01 = (g.sel & (1u << 25)) ? r.t01 : 0.0f;

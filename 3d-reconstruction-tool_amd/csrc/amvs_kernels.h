@@ -86,7 +86,8 @@ hipError_t launch_box_stats(int K, const float *images, long long img_stride, in
                             int first_img, int n_img, float *mean_out, float *var_out,
                             hipStream_t st);
 long long pair_map_elems(int H, int W);      // ushorts of one zero-bordered packed map
-long long pair_map_origin(int W);            // ushort offset of image pixel (0,0) inside it
+long long pair_map_origin(int W);            // texel offset of image pixel (0,0) inside it
+int pair_map_texel_bytes();                  // 2 (row-pair layout) or 1 (byte layout)
 hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, int *inexact,
                              hipStream_t st);
 hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,

@@ -101,6 +101,9 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 
 // Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
 // (1) or after every operation / source (0).  The plane sweep always uses the per-row form (+3 %).
+#if AMVS_CODE_BYTES && !AMVS_NO_PAIRS
+#error "the packed source-pair path only exists for the row-pair map layout"
+#endif
 #ifndef AMVS_RELOAD_STRIDE
 #define AMVS_RELOAD_STRIDE 1
 #endif
@@ -179,8 +182,8 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
             const PairScalars c = load_pair_scalars(jr, s / 2);
             const TapGeomPair tg = sample_geom_pair(c.K, c.R, c.t, c.gc, sc, Pw, live, ok0, ok1);
             okbits |= (ok0 ? (1u << s) : 0u) | (ok1 ? (2u << s) : 0u);
-            const uint32_t w0 = load_pair_word(c.img[0], tg.off[0]);
-            const uint32_t w1 = load_pair_word(c.img[1], tg.off[1]);
+            const uint32_t w0 = load_pair_word(c.img[0], tg.off[0], 0);
+            const uint32_t w1 = load_pair_word(c.img[1], tg.off[1], 0);
             AMVS_TMARK(1, false);
             AMVS_TMARK(2, true);
             const v2f vp = sample_finish_pair(w0, w1, tg, lut, live);
@@ -208,7 +211,7 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
             tg[s] = sample_geom<U8, LEAN>(Kc, c.R, c.t, sc, Pw, live, valid, ok);
         }
         okbits |= valid ? (1u << s) : 0u;
-        tr[s] = sample_load<U8>(c.img, tg[s]);
+        tr[s] = sample_load<U8>(c.img, tg[s], sc.W + 2 * AMVS_PAIR_BORDER);
 #ifdef AMVS_GATHER_SERIAL    // previous structure: decode each source right after its gather
         AMVS_TMARK(1, false);
         AMVS_TMARK(2, true);
@@ -481,6 +484,11 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     // ref gray of the packed path: low byte of the padded row-pair map (pitch W+4, origin at pixel (0,0))
     const uint16_t *__restrict__ ref_pairs = U8 ? (const uint16_t *)job->ref_pairs : a.pairs;
     constexpr int PADW = U8 ? 2 * AMVS_PAIR_BORDER : 0;
+#if AMVS_CODE_BYTES
+#define AMVS_REF_CODE(i) (((const uint8_t *)ref_pairs)[i])
+#else
+#define AMVS_REF_CODE(i) (ref_pairs[i])
+#endif
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
     const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const bool live_n = col_in & ((unsigned)yn < (unsigned)H);
         const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         pf_d = d_in[inb_n ? yn * W + xr + noff : 0];
-        pf_r = U8 ? (uint32_t)ref_pairs[live_n ? yn * (W + PADW) + xr : 0] : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
+        pf_r = U8 ? (uint32_t)AMVS_REF_CODE(live_n ? yn * (W + PADW) + xr : 0) : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
     }
 #endif
     for (int r = 0; r < rows_wg; ++r) {
@@ -562,13 +570,13 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             const bool live_n = col_in & ((unsigned)yn < (unsigned)H) & (r + 1 < rows);
             const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
             pf_d = d_in[inb_n ? pix + W + noff : 0];
-            pf_r = U8 ? (uint32_t)ref_pairs[live_n ? pix + W + PADW * (yr + 1) : 0] : __float_as_uint(ref[live_n ? pix + W : 0]);
+            pf_r = U8 ? (uint32_t)AMVS_REF_CODE(live_n ? pix + W + PADW * (yr + 1) : 0) : __float_as_uint(ref[live_n ? pix + W : 0]);
         }
 #else
         const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
-        const float r_raw = U8 ? lut[ref_pairs[AMVS_SIDX(live ? pix + PADW * yr : 0)] & 0xFFu]
+        const float r_raw = U8 ? lut[AMVS_REF_CODE(AMVS_SIDX(live ? pix + PADW * yr : 0)) & 0xFFu]
                                : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
 #endif
 
@@ -986,7 +994,11 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict
         const int c0 = min(max((int)__builtin_rintf(g0 * 255.0f), 0), 255);
         const int c1 = min(max((int)__builtin_rintf(g1 * 255.0f), 0), 255);
         if (in0 & !((float)c0 / 255.0f == g0)) atomicOr(inexact, 1);
+#if AMVS_CODE_BYTES
+        ((uint8_t *)pairs)[i] = (uint8_t)c0;
+#else
         pairs[i] = (uint16_t)(c0 | (c1 << 8));
+#endif
     }
 }
 
@@ -1006,6 +1018,7 @@ long long pair_map_elems(int H, int W)
 }
 // ushort offset of image pixel (0,0) inside a padded map
 long long pair_map_origin(int W) { return (long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER; }
+int pair_map_texel_bytes() { return AMVS_CODE_BYTES ? 1 : 2; }
 
 // ------------------------------------------------------------------ init ---------
 // depth = exp(rand*(ln dmax - ln dmin) + ln dmin); normal = normalize(randn*0.3,
