@@ -171,11 +171,6 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
         j.stream_view = (uint32_t)r;
         j.slot = i;
         j.n_src = n_src;
-        {
-            const float fw = (float)(c->W - 1), fh = (float)(c->H - 1);
-            const float gc[6] = {fw, fh, 1.0f / fw, 1.0f / fh, fw * 0.5f, fh * 0.5f};
-            for (int e = 0; e < 6; ++e) j.gridc[e][0] = j.gridc[e][1] = gc[e];
-        }
         for (int s = 0; s < n_src; ++s) {
             const int v = src_ids[i * n_src + s];
             if (v < 0 || v >= c->n_views || !c->have[v])
@@ -184,8 +179,6 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             j.src[s].gray = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
             std::memcpy(j.src[s].R, c->R[v].data(), 36);
             std::memcpy(j.src[s].t, c->t[v].data(), 12);
-            for (int e = 0; e < 9; ++e) j.RsP[s / 2][e][s & 1] = c->R[v][e];
-            for (int e = 0; e < 3; ++e) j.tsP[s / 2][e][s & 1] = c->t[v][e];
         }
     }
     int rc = ensure_jobs(c, n_ref);

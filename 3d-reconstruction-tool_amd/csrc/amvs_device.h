@@ -216,34 +216,6 @@ AMVS_DEV float qdiv(float a, float b, float rb)
     return __builtin_fmaf(r, rb, q);
 }
 
-// ---- two-wide (packed fp32) forms ----
-// gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two IEEE float32 operations per lane,
-// the same roundings as the scalar forms) at nearly the rate of one scalar VALU operation
-// (tools/valu_rate.hip), so arithmetic that is identical for two source views runs on a pair.
-typedef float v2f __attribute__((ext_vector_type(2)));
-AMVS_DEV v2f splat2(float x) { return (v2f){x, x}; }
-AMVS_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-
-AMVS_DEV v2f rcp_rn2(v2f x)
-{
-    v2f r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
-    const v2f e = fma2(-x, r, splat2(1.0f));
-    r = fma2(r, e, r);
-    const bool ok0 = lean_exp_ok(x.x), ok1 = lean_exp_ok(x.y);
-    if (__builtin_expect(!__all(ok0 & ok1), 0)) {
-        r.x = ok0 ? r.x : 1.0f / x.x;
-        r.y = ok1 ? r.y : 1.0f / x.y;
-    }
-    return r;
-}
-
-AMVS_DEV v2f qdiv2(v2f a, v2f b, v2f rb)
-{
-    const v2f q = a * rb;
-    const v2f r = fma2(-q, b, a);
-    return fma2(r, rb, q);
-}
-
 // F.normalize(v, dim=-1) = v / max(||v||, 1e-12)   (mvs_patchmatch.py:281,476)
 AMVS_DEV void normalize3(float &x, float &y, float &z)
 {
@@ -470,70 +442,6 @@ AMVS_DEV float sample_finish(const TapRaw<U8> &r, const TapGeom<U8> &g, const fl
     }
     float v = __builtin_fmaf(t11, g.se, __builtin_fmaf(t10, g.sw, __builtin_fmaf(t01, g.ne, t00 * g.nw)));
     return live ? v : 0.0f;
-}
-
-// ---- two sources at a time (packed 8-bit maps only) ----
-// Same arithmetic as sample_geom / sample_finish, element for element; RsP / tsP hold the two
-// poses interleaved ([i][2]) so that a matrix entry of both views is one 64-bit scalar operand.
-struct TapGeomPair {
-    v2f nw, ne, sw, se;
-    int off[2];
-};
-
-template <class KP, class RPP, class TPP, class GPP>
-AMVS_DEV TapGeomPair sample_geom_pair(KP K, RPP RsP, TPP tsP, GPP gc, const SampleConsts &c, Vec3 Pw, bool live,
-                                      bool &valid0, bool &valid1)
-{
-    const int W = c.W;
-    // gc: W-1, H-1, their reciprocals and halves, each as a scalar-register pair
-#define AMVS_GC(i) (gc[i])
-    const v2f X = splat2(Pw.x), Y = splat2(Pw.y), Z = splat2(Pw.z);
-#define AMVS_PR(i) (RsP[i])
-#define AMVS_PT(i) (tsP[i])
-    const v2f p0 = fma2(Z, AMVS_PR(2), fma2(Y, AMVS_PR(1), X * AMVS_PR(0))) + AMVS_PT(0);
-    const v2f p1 = fma2(Z, AMVS_PR(5), fma2(Y, AMVS_PR(4), X * AMVS_PR(3))) + AMVS_PT(1);
-    const v2f z = fma2(Z, AMVS_PR(8), fma2(Y, AMVS_PR(7), X * AMVS_PR(6))) + AMVS_PT(2);
-#undef AMVS_PR
-#undef AMVS_PT
-    const v2f zz = z + splat2(1e-8f);
-    const v2f rz = rcp_rn2(zz);
-    const v2f a = qdiv2(p0, zz, rz), b = qdiv2(p1, zz, rz);
-    const v2f u = fma2(b, splat2(K[1]), a * splat2(K[0])) + splat2(K[2]);
-    const v2f v = fma2(b, splat2(K[4]), a * splat2(K[3])) + splat2(K[5]);
-    valid0 = (z.x > 0.1f) & (u.x >= c.lo) & (u.x < c.hix) & (v.x >= c.lo) & (v.x < c.hiy);
-    valid1 = (z.y > 0.1f) & (u.y >= c.lo) & (u.y < c.hix) & (v.y >= c.lo) & (v.y < c.hiy);
-    const v2f gx = qdiv2(splat2(2.0f) * u, AMVS_GC(0), AMVS_GC(2)) - splat2(1.0f);
-    const v2f gy = qdiv2(splat2(2.0f) * v, AMVS_GC(1), AMVS_GC(3)) - splat2(1.0f);
-    const v2f ux = (gx + splat2(1.0f)) * AMVS_GC(4);
-    const v2f uy = (gy + splat2(1.0f)) * AMVS_GC(5);
-#undef AMVS_GC
-    const v2f x0 = {__builtin_floorf(ux.x), __builtin_floorf(ux.y)};
-    const v2f y0 = {__builtin_floorf(uy.x), __builtin_floorf(uy.y)};
-    const v2f x1 = x0 + splat2(1.0f), y1 = y0 + splat2(1.0f);
-    const v2f wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
-    TapGeomPair g;
-    g.nw = wx0 * wy0; g.ne = wx1 * wy0; g.sw = wx0 * wy1; g.se = wx1 * wy1;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int cx = (int)__builtin_amdgcn_fmed3f(h ? x0.y : x0.x, -(float)AMVS_PAIR_BORDER, gc[0].x + 1.0f);
-        const int cy = (int)__builtin_amdgcn_fmed3f(h ? y0.y : y0.x, -(float)AMVS_PAIR_BORDER, gc[1].x + 1.0f);
-        const unsigned idx = __umul24((unsigned)(cy + AMVS_PAIR_BORDER), (unsigned)(W + 2 * AMVS_PAIR_BORDER)) +
-                             (unsigned)(cx + AMVS_PAIR_BORDER);
-        g.off[h] = live ? (int)idx : 0;
-    }
-    return g;
-}
-
-AMVS_DEV v2f sample_finish_pair(uint32_t w0, uint32_t w1, const TapGeomPair &g, const float *lut, bool live)
-{
-    const v2f t00 = {lut[w0 & 0xFFu], lut[w1 & 0xFFu]};
-    const v2f t10 = {lut[(w0 >> 8) & 0xFFu], lut[(w1 >> 8) & 0xFFu]};
-    const v2f t01 = {lut[(w0 >> 16) & 0xFFu], lut[(w1 >> 16) & 0xFFu]};
-    const v2f t11 = {lut[w0 >> 24], lut[w1 >> 24]};
-    v2f v = fma2(t11, g.se, fma2(t10, g.sw, fma2(t01, g.ne, t00 * g.nw)));
-    v.x = live ? v.x : 0.0f;
-    v.y = live ? v.y : 0.0f;
-    return v;
 }
 
 // fill the 256-entry code -> gray table (one wave; entry c = (float)c / 255.0f, the

@@ -28,12 +28,6 @@ struct alignas(64) Job {
     int n_src;
     unsigned long long ref_pairs;   // image pixel (0,0) of the reference view's packed map
     SrcEntry src[AMVS_KMAX_SRC];
-    // the same poses, two sources interleaved ([pair][entry][2]): one 64-bit scalar operand per
-    // matrix entry for the packed-fp32 projection of a source pair (-DAMVS_NO_PAIRS=0)
-    float RsP[AMVS_KMAX_SRC / 2][9][2], tsP[AMVS_KMAX_SRC / 2][3][2];
-    // sampler constants, each duplicated into a pair for the same reason:
-    // W-1, H-1, RN(1/(W-1)), RN(1/(H-1)), (W-1)/2, (H-1)/2
-    float gridc[6][2];
 };
 
 enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };

@@ -38,11 +38,6 @@ AMVS_DEV JobCP reload(JobCP p)
     asm volatile("" : "+s"(p));
     return p;
 }
-#ifdef AMVS_ABLATE_ROW_RELOAD      // experiment: one reload per row instead of one per source
-#define AMVS_SRC_RELOAD(p) (p)
-#else
-#define AMVS_SRC_RELOAD(p) reload(p)
-#endif
 
 // timing-only ablations (results are wrong when any is defined)
 #ifdef AMVS_ABL_LOCALSTREAM
@@ -51,15 +46,10 @@ AMVS_DEV JobCP reload(JobCP p)
 #define AMVS_SIDX(i) (i)
 #endif
 
-// Streaming state is touched once per launch; the packed source maps are re-read by every strip.
-// Non-temporal hints on the former keep them from evicting the latter from L2 / Infinity Cache.
-#ifdef AMVS_NT            // measured: no effect on MI355X (31.8 vs 31.7 G px-hyp/s), off by default
-#define AMVS_LDS_STREAM(p) __builtin_nontemporal_load(p)
-#define AMVS_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
-#else
+// (Non-temporal hints on the streaming state were measured without effect on MI355X -- 31.8 vs 31.7
+// G px-hyp/s -- and are not used.)
 #define AMVS_LDS_STREAM(p) (*(p))
 #define AMVS_ST_STREAM(p, v) (*(p) = (v))
-#endif
 
 // contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
 AMVS_DEV int xcd_remap(int bid, int nblk)
@@ -90,20 +80,13 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 #define AMVS_TM_ARG
 #endif
 
-// -DAMVS_NO_PAIRS=0 samples the sources two at a time with packed fp32 arithmetic (sample_geom_pair:
-// 5 % fewer VALU instructions, two gather waits per row instead of four, bit-identical results).
-// Measured on MI355X (16 views 1080p, k=7, S=4) it is 2 % SLOWER than the scalar path (33.5 vs 34.1
-// G px-hyp/s): packed operations want wait states after most producers and the interleaved pose
-// table costs more scalar loads, so the scalar path stays the default.
-#ifndef AMVS_NO_PAIRS
-#define AMVS_NO_PAIRS 1
-#endif
-
 // Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
-// (1) or after every operation / source (0).  The plane sweep always uses the per-row form (+3 %).
-#if AMVS_CODE_BYTES && !AMVS_NO_PAIRS
-#error "the packed source-pair path only exists for the row-pair map layout"
-#endif
+// (1) or after every operation / source (0, measured 2 % faster there).  The plane sweep always
+// uses the per-row form (+3 %).  AMVS_RELOAD_STRIDE sources share one opaque pointer copy (which
+// is also a scheduling barrier), so their arithmetic can interleave; 1 is fastest (registers).
+// (Sampling the sources two at a time with packed fp32 arithmetic -- v_pk_fma/mul/add_f32 on pose
+// pairs interleaved in the job table, 5 % fewer VALU instructions, bit-identical -- was measured
+// 1-2 % slower in three different states of this kernel and is no longer carried in the source.)
 #ifndef AMVS_RELOAD_STRIDE
 #define AMVS_RELOAD_STRIDE 1
 #endif
@@ -115,8 +98,7 @@ AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
 #endif
 
 // The scalar operands of one source: one 64-byte record of the job table (SrcEntry), i.e. one
-// s_load_dwordx16 and one wait.  (-DAMVS_SMEM_BATCH additionally pins them as a batch; the
-// compiler already keeps them together.)
+// batch of scalar loads and one wait.
 struct SrcScalars { float R[9], t[3]; unsigned long long img; };
 AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 {
@@ -126,40 +108,10 @@ AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 #pragma unroll
     for (int i = 0; i < 3; ++i) c.t[i] = jr->src[s].t[i];
     c.img = u8 ? jr->src[s].pairs : jr->src[s].gray;
-#ifdef AMVS_SMEM_BATCH
-    asm volatile("" : "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
-                 "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]), "+s"(c.img));
-#endif
     return c;
 }
 
-struct PairScalars { float K[6]; v2f R[9], t[3], gc[6]; unsigned long long img[2]; };
-AMVS_DEV PairScalars load_pair_scalars(JobCP jr, int pr)
-{
-    PairScalars c;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) c.K[i] = jr->K[i];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = (v2f){jr->RsP[pr][i][0], jr->RsP[pr][i][1]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c.t[i] = (v2f){jr->tsP[pr][i][0], jr->tsP[pr][i][1]};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) c.gc[i] = (v2f){jr->gridc[i][0], jr->gridc[i][1]};
-    c.img[0] = jr->src[2 * pr].pairs;
-    c.img[1] = jr->src[2 * pr + 1].pairs;
-#ifdef AMVS_SMEM_BATCH
-    asm volatile("" : "+s"(c.K[0]), "+s"(c.K[1]), "+s"(c.K[2]), "+s"(c.K[3]), "+s"(c.K[4]), "+s"(c.K[5]),
-                 "+s"(c.R[0]), "+s"(c.R[1]), "+s"(c.R[2]), "+s"(c.R[3]), "+s"(c.R[4]), "+s"(c.R[5]), "+s"(c.R[6]),
-                 "+s"(c.R[7]), "+s"(c.R[8]), "+s"(c.t[0]), "+s"(c.t[1]), "+s"(c.t[2]),
-                 "+s"(c.gc[0]), "+s"(c.gc[1]), "+s"(c.gc[2]), "+s"(c.gc[3]), "+s"(c.gc[4]), "+s"(c.gc[5]),
-                 "+s"(c.img[0]), "+s"(c.img[1]));
-#endif
-    return c;
-}
-
-// Sample all S sources of one pixel, source by source.  (Issuing the geometry of every source
-// first and the S gathers back to back was measured slower on MI355X -- 22.7 / 25.2 G px-hyp/s at
-// 128 / 147 VGPRs vs 26.9 -- and is no longer carried in the source.)
+// Sample all S sources of one pixel.
 // LEAN / `ok`: optimistic lean reciprocal (amvs_device.h).  SRC_CHECK = true tests `ok` after each
 // source's geometry and repeats that geometry with IEEE arithmetic (one wave-uniform branch per
 // source); SRC_CHECK = false leaves the test to the caller (one branch per row).
@@ -173,35 +125,16 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
     float Kc[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) Kc[i] = jr->K[i];
-    constexpr int SP = (U8 && !AMVS_NO_PAIRS) ? (S & ~1) : 0;     // sources handled as pairs
-    if constexpr (U8) {
-#pragma unroll
-        for (int s = 0; s < SP; s += 2) {
-            bool ok0, ok1;
-            jr = AMVS_SRC_RELOAD(jr);
-            const PairScalars c = load_pair_scalars(jr, s / 2);
-            const TapGeomPair tg = sample_geom_pair(c.K, c.R, c.t, c.gc, sc, Pw, live, ok0, ok1);
-            okbits |= (ok0 ? (1u << s) : 0u) | (ok1 ? (2u << s) : 0u);
-            const uint32_t w0 = load_pair_word(c.img[0], tg.off[0], 0);
-            const uint32_t w1 = load_pair_word(c.img[1], tg.off[1], 0);
-            AMVS_TMARK(1, false);
-            AMVS_TMARK(2, true);
-            const v2f vp = sample_finish_pair(w0, w1, tg, lut, live);
-            v[s] = vp.x; v[s + 1] = vp.y;
-        }
-    }
     // Geometry of every source first, each gather issued as soon as its address exists, then the
-    // decodes: the S gather latencies overlap (one exposed wait per row instead of S).  The taps'
-    // weights wait in registers meanwhile (5 per source) -- affordable since the window-sum stage,
-    // not the sampling stage, sets this kernel's register peak.
+    // decodes: the S gather latencies overlap (one exposed wait per row instead of S: +3 %).  The
+    // taps' weights wait in registers meanwhile (4 per source) -- affordable since the window-sum
+    // stage, not the sampling stage, sets this kernel's register peak.
     TapGeom<U8> tg[S];
     TapRaw<U8> tr[S];
 #pragma unroll
-    for (int s = SP; s < S; ++s) {
+    for (int s = 0; s < S; ++s) {
         bool valid;
-        // (the opaque pointer copy that keeps the scalar loads inside the loop is also a scheduling
-        // barrier: AMVS_RELOAD_STRIDE sources share one, so their arithmetic can interleave)
-        if ((s - SP) % AMVS_RELOAD_STRIDE == 0) jr = AMVS_SRC_RELOAD(jr);
+        if (s % AMVS_RELOAD_STRIDE == 0) jr = reload(jr);
         const SrcScalars c = load_src_scalars(jr, s, U8);
         if constexpr (SRC_CHECK) {
             bool ok_s = true;
@@ -212,18 +145,11 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
         }
         okbits |= valid ? (1u << s) : 0u;
         tr[s] = sample_load<U8>(c.img, tg[s], sc.W + 2 * AMVS_PAIR_BORDER);
-#ifdef AMVS_GATHER_SERIAL    // previous structure: decode each source right after its gather
-        AMVS_TMARK(1, false);
-        AMVS_TMARK(2, true);
-        v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
-#endif
     }
-#ifndef AMVS_GATHER_SERIAL
     AMVS_TMARK(1, false);
 #pragma unroll
-    for (int s = SP; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
+    for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
     AMVS_TMARK(2, false);
-#endif
     return okbits;
 }
 
@@ -431,12 +357,11 @@ AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *
 }
 
 // AMVS_WG_WAVES adjacent strips share one workgroup (one CU, started together), so the source
-// sectors their epipolar bands have in common are fetched while they are still in L1 / L2.
+// sectors their epipolar bands have in common are fetched while they are still in L1 / L2: with 10
+// the HBM-side traffic halves -- and the launch gets slower, because a 5- or
+// 10-wave workgroup fits only twice / once per CU.  1 is the default; 2 and 4 measure the same.
 #ifndef AMVS_WG_WAVES
 #define AMVS_WG_WAVES 1
-#endif
-#ifndef AMVS_WG_SYNC_ROWS          // barrier every this many rows keeps the strips in step (0: never)
-#define AMVS_WG_SYNC_ROWS 0
 #endif
 
 template <int K, int S, bool U8>
@@ -463,14 +388,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
-#ifdef AMVS_WG_SCATTER      // timing experiment: same workgroup shape, strips far apart
-    int t = xcd_remap(blockIdx.x, gridDim.x) + wv * (int)gridDim.x;
-#else
-    int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
-#endif
-    const bool idle_wave = t >= a.n_jobs * tiles_per_job;      // last workgroup only
-    if (AMVS_WG_SYNC_ROWS == 0 && idle_wave) return;
-    t = idle_wave ? 0 : t;
+    const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
+    if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
     const int job_id = t / tiles_per_job;
     const int rem = t - job_id * tiles_per_job;
     const int ty = rem / a.tiles_x;
@@ -508,8 +427,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     const int y0 = ty * a.TH;
     const int xr = xbase + lane;
     const bool col_in = (unsigned)xr < (unsigned)W;
-    const int rows = idle_wave ? 0 : min(a.TH, H - y0) + 2 * HALF;
-    const int rows_wg = AMVS_WG_SYNC_ROWS ? a.TH + 2 * HALF : rows;
+    const int rows = min(a.TH, H - y0) + 2 * HALF;
 
     float ring_r[K];
     float ring_v[Ring<S>::NR][K];
@@ -541,44 +459,16 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     tm.last = __builtin_amdgcn_s_memtime();
 #endif
 
-#ifdef AMVS_PREFETCH_ROW
-    float pf_d;
-    uint32_t pf_r;
-    {
-        const int yn = y0 - HALF;
-        const bool live_n = col_in & ((unsigned)yn < (unsigned)H);
-        const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
-        pf_d = d_in[inb_n ? yn * W + xr + noff : 0];
-        pf_r = U8 ? (uint32_t)AMVS_REF_CODE(live_n ? yn * (W + PADW) + xr : 0) : __float_as_uint(ref[live_n ? yn * W + xr : 0]);
-    }
-#endif
-    for (int r = 0; r < rows_wg; ++r) {
-        if (AMVS_WG_SYNC_ROWS && AMVS_WG_WAVES > 1) {
-            if (r % (AMVS_WG_SYNC_ROWS ? AMVS_WG_SYNC_ROWS : 1) == 0) __builtin_amdgcn_s_barrier();
-            if (r >= rows) continue;
-        }
+    for (int r = 0; r < rows; ++r) {
         const int yr = y0 - HALF + r;
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-#ifdef AMVS_PREFETCH_ROW
-        // depth and ref gray of the next row are requested a whole row ahead of their use
-        const float d_raw = pf_d;
-        const float r_raw = U8 ? lut[pf_r & 0xFFu] : __uint_as_float(pf_r);
-        {
-            const int yn = yr + 1;
-            const bool live_n = col_in & ((unsigned)yn < (unsigned)H) & (r + 1 < rows);
-            const bool inb_n = live_n & ((unsigned)(yn + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
-            pf_d = d_in[inb_n ? pix + W + noff : 0];
-            pf_r = U8 ? (uint32_t)AMVS_REF_CODE(live_n ? pix + W + PADW * (yr + 1) : 0) : __float_as_uint(ref[live_n ? pix + W : 0]);
-        }
-#else
         const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
         const float r_raw = U8 ? lut[AMVS_REF_CODE(AMVS_SIDX(live ? pix + PADW * yr : 0)) & 0xFFu]
                                : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
-#endif
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
@@ -737,7 +627,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
             if (act) AMVS_ST_STREAM(&d_out[pc], better ? d : oldd);
-#ifndef AMVS_ABL_NONORMAL
             // The winners' normals (normalize(normal + randn*range), mvs_patchmatch.py:475-476) are
             // not updated here: a row has ~3 winners among its 58 pixels, yet the ~150-instruction
             // update would run for the whole wave on almost every row.  Winners are queued in LDS
@@ -754,7 +643,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
                     q_head += AMVS_WAVE;
                 }
             }
-#endif
         }
         AMVS_TMARK(5, false);
     }
