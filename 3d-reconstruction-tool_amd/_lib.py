@@ -67,6 +67,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_int64)]),
     "amvs_fetch_cloud": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
     "amvs_write_ply": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64]),
+    "amvs_knn_mean_distance": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "amvs_selftest_lean_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "amvs_rng_fill": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, f32p, f32p]),
 }

@@ -863,6 +863,19 @@ int amvs_fetch_cloud(amvs_ctx *c, double *points, uint8_t *colors)
 
 // utils.save_ply (utils.py:8-37): ASCII PLY, "%.6f %.6f %.6f %d %d %d" per vertex.  Host-only:
 // formats into a 1 MiB buffer instead of one Python f.write per point.
+int amvs_knn_mean_distance(amvs_ctx *c, const double *points, int64_t n, int k, double *mean_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!points || !mean_out || n < 1) return fail(c, AMVS_EINVAL, "NULL argument / empty cloud");
+    if (!amvs::knn_supported(k)) return fail(c, AMVS_EUNSUPPORTED, "k not compiled in (8, 10, 16, 20, 32)");
+    if (n < k) return fail(c, AMVS_EINVAL, "fewer points than neighbours");
+    if (n > (1ll << 30)) return fail(c, AMVS_EINVAL, "cloud too large (32-bit point indices)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, amvs::knn_mean_distance(points, (long long)n, k, mean_out, c->stream));
+    return AMVS_OK;
+}
+
 int amvs_write_ply(const char *path, const double *points, const int64_t *colors, int64_t n)
 {
     if (!path || n < 0 || (n > 0 && (!points || !colors))) return fail(nullptr, AMVS_EINVAL, "bad argument");

@@ -71,6 +71,8 @@ struct SweepArgs : StepArgsBase {
 };
 
 bool patch_supported(int K);
+bool knn_supported(int k);
+hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st);
 int strip_out_width(int K);
 int step_waves_per_cu(int K, int S, bool u8);
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);

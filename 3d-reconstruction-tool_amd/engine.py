@@ -233,6 +233,15 @@ class Engine:
                                                  rgb.ctypes.data_as(C.POINTER(C.c_uint8))))
         return pts, rgb, int(counts[0])
 
+    def knn_mean_distance(self, points, k=20):
+        """Mean distance of every point to its k-1 nearest other points, bit-identical to
+        np.mean(NearestNeighbors(n_neighbors=k).fit(p).kneighbors(p)[0][:, 1:], axis=1)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.empty(pts.shape[0], np.float64)
+        self._chk(self._lib.amvs_knn_mean_distance(self._h, pts.ctypes.data_as(C.POINTER(C.c_double)),
+                                                   pts.shape[0], int(k), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def selftest_lean_math(self):
         """(reciprocal mismatches, sqrt mismatches) against IEEE over all 2^32 float patterns."""
         out = (C.c_uint64 * 2)()

@@ -110,6 +110,15 @@ int amvs_plane_sweep_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const 
                             int n_nbr, const float *depths, int D, int patch_size,
                             float thresh, void *depth_dev, void *conf_dev);
 
+/* The k-nearest-neighbour statistic of DenseStereoReconstructor._filter_outliers
+ * (dense_stereo.py:456-460: NearestNeighbors(n_neighbors=k).fit(p).kneighbors(p), then
+ * np.mean(distances[:, 1:], axis=1)) for n points (host, n x 3 float64) on the device: mean_out[i]
+ * = mean distance from point i to its k-1 nearest other points, bit-identical to scikit-learn +
+ * numpy (same float64 distance expression, same summation order) wherever scikit-learn uses its
+ * KD-tree (k < n / 2; for smaller clouds it switches to a brute-force kernel whose rounding differs
+ * by a few ulps).  k in {8, 10, 16, 20, 32}, n >= k.  The threshold mean + 2 sigma and the selection stay on the host (numpy), as there.    */
+int amvs_knn_mean_distance(amvs_ctx *ctx, const double *points, int64_t n, int k, double *mean_out);
+
 /* PatchMatchMVS._fuse_depth_maps + _filter_points (mvs_patchmatch.py:536-588) on the device, in
  * float64 and in the reference's order: pixels with confidence >= min_views of n_maps maps
  * ([n_maps][H][W] float32, host or device memory) are back-projected with the float64 K_inv and

@@ -417,6 +417,64 @@ def test_device_fusion_matches_numpy_on_sweep_output(amvs_mod):
 
 
 # ------------------------------------------------------------------ error paths ---
+def _knn_clouds():
+    rng = np.random.default_rng(77)
+    clouds = {}
+    # a reconstructed-surface-like cloud: two noisy sheets
+    xy = rng.uniform(-2.0, 2.0, (20000, 2))
+    z = 0.15 * np.sin(1.3 * xy[:, 0]) * np.cos(1.7 * xy[:, 1]) + rng.normal(0, 0.004, 20000)
+    sheet = np.column_stack([xy, z])
+    clouds["sheets"] = np.vstack([sheet, sheet[:5000] * [1.0, 1.0, -1.0] + [0.0, 0.0, 1.0]])
+    # exact duplicates (several zero distances) and far outliers (long shell walks)
+    dup = sheet[:3000].copy()
+    dup[100:160] = dup[7]
+    dup[-5:] = [[40.0, 0, 0], [0, -55.0, 3], [9.0, 9.0, 9.0], [-30.0, 30.0, 0.5], [40.001, 0, 0]]
+    clouds["duplicates+outliers"] = dup
+    clouds["few points"] = rng.normal(size=(45, 3))          # smallest size scikit-learn still uses its KD-tree for
+    line = np.zeros((400, 3))
+    line[:, 0] = np.sort(rng.uniform(0, 1, 400))           # degenerate extents in y and z
+    clouds["line"] = line
+    clouds["volume float32 values"] = rng.uniform(-1, 1, (6000, 3)).astype(np.float32).astype(np.float64)
+    return clouds
+
+
+def test_knn_mean_distance_matches_sklearn(eng_a):
+    """amvs_knn_mean_distance against the reference's own expression (dense_stereo.py:456-460:
+    scikit-learn kneighbors + np.mean over distances[:, 1:]): bit-identical float64."""
+    NearestNeighbors = pytest.importorskip("sklearn.neighbors").NearestNeighbors
+    for name, pts in _knn_clouds().items():
+        for k in ((20, 8) if name == "sheets" else (20,)):
+            dists, _ = NearestNeighbors(n_neighbors=k).fit(pts).kneighbors(pts)
+            want = np.mean(dists[:, 1:], axis=1)
+            got = eng_a.knn_mean_distance(pts, k)
+            assert got.dtype == np.float64 and got.shape == want.shape
+            bad = got != want
+            assert not bad.any(), f"{name}, k={k}: {int(bad.sum())} of {len(want)} means differ, " \
+                                  f"max |diff| {np.abs(got - want).max():.3e}"
+    # below n = 2k + 2 scikit-learn switches to its brute-force kernel (|x|^2 + |y|^2 - 2xy, a few
+    # ulps off the direct expression): same neighbours, values equal to rounding only
+    tiny = np.random.default_rng(3).normal(size=(21, 3))
+    dists, _ = NearestNeighbors(n_neighbors=20).fit(tiny).kneighbors(tiny)
+    np.testing.assert_allclose(eng_a.knn_mean_distance(tiny, 20), np.mean(dists[:, 1:], axis=1), rtol=1e-12)
+
+
+def test_stereo_outlier_filter_device_equals_host(eng_a, amvs_mod):
+    """DenseStereoReconstructor._filter_outliers with the device neighbour search selects exactly
+    the points the scikit-learn path selects."""
+    pytest.importorskip("sklearn.neighbors")
+    from amvs.core.dense_stereo import DenseStereoReconstructor
+    pts = _knn_clouds()["sheets"]
+    cols = (np.arange(len(pts) * 3) % 251).astype(np.uint8).reshape(-1, 3)
+    cam = amvs_mod.Camera(K=np.array([[500.0, 0, 320], [0, 500.0, 240], [0, 0, 1]]), dist=np.zeros(5))
+    rec = DenseStereoReconstructor(cam, scale=1.0)
+    host_p, host_c = rec._filter_outliers(pts, cols)             # no engine yet: scikit-learn
+    rec._engine = eng_a
+    dev_p, dev_c = rec._filter_outliers(pts, cols)
+    rec._engine = None
+    assert 0 < len(host_p) < len(pts)
+    assert np.array_equal(dev_p, host_p) and np.array_equal(dev_c, host_c)
+
+
 def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
     d = scene_a.gt_depth[2]
