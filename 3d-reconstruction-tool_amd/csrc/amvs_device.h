@@ -275,7 +275,7 @@ AMVS_DEV SampleConsts make_sample_consts(int H, int W, float lo, float hix, floa
 // ALL its sources back to back (one exposed memory latency per row instead of one per source):
 //   sample_geom   project + bounds test + bilinear weights + addresses       (pure VALU)
 //   sample_load   the gather(s)                                              (VMEM)
-//   sample_finish decode + masked 4-tap fma chain                            (LDS + VALU)
+//   sample_finish decode + 4-tap fma chain                                   (LDS + VALU)
 //
 // Reference: mvs_patchmatch.py:351-377 (project, bounds test, grid_sample bilinear / zeros /
 // align_corners=True), restated bit-exactly against ATen's CPU kernel.  The projection is

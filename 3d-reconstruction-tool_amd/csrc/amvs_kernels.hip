@@ -184,8 +184,8 @@ template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
 
 // Where the vertical rings live.  The ref ring and the rings of the first NL sources are kept in
 // LDS ([ring][slot][lane], rotating slot, conflict-free one-dword-per-lane accesses) instead of
-// registers: 7*(NL+1) fewer VGPRs held across the whole row loop (the sampling phase is the
-// register peak), which is what lets the k=7, S=4 kernel run five waves per SIMD; the other
+// registers: 7*(NL+1) fewer VGPRs held across the whole row loop, which is what lets the k=7, S=4
+// kernel run five waves per SIMD (the window-sum stage is its register peak today); the other
 // sources stay in shifting register rings.
 #ifndef AMVS_RING_LDS_SOURCES
 #define AMVS_RING_LDS_SOURCES 2
@@ -447,11 +447,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     // (mvs_patchmatch.py:431-441), the pixel itself ((0,0)) for every other mode.  All loads use
     // clamped indices (dead lanes read element 0), so there is no branch in the load path.
     //
-    // Measured alternatives that did NOT pay on MI355X (16 views 1080p, k=7, S=4):
-    // issuing the S gathers of a row together (-15 %: +24 VGPRs), software-pipelining the row
-    // loop by one row (requests of row r+1 behind the epilogue of row r: -2 %, +60 VGPRs).
-    // Timing-only ablations show why: with every load served from L1 and no stores the launch
-    // still takes 82 % of its time -- the kernel is bound by instruction issue, not by memory.
+    // The launch time follows the instruction stream: software-pipelining the
+    // row loop by one row (requests of row r+1 behind the epilogue of row r) measured -2 % at +60
+    // VGPRs, requesting the next row's depth / ref gray a row ahead measured nothing.
     const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
     const int noff = oy * W + ox;
 #ifdef AMVS_TIMERS
