@@ -48,6 +48,33 @@ AMVS_DEV float sqrt_rn(float x)
     return g;
 }
 
+// 1 / (sqrt(x) + 1e-8) pieces of the NCC denominator (mvs_patchmatch.py:409-411) with ONE validity
+// test: when x passes the square root's test (2^-95 <= x < 2^96, or zero) the denominator lies in
+// [1e-8, 2^48], always inside the reciprocal's verified range, so the reciprocal needs no test of
+// its own; otherwise both run as IEEE operations.
+AMVS_DEV void ncc_denominator(float x, float &den, float &rden)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    g = x == 0.0f ? x : g;
+    den = g + 1e-8f;
+    float q = __builtin_amdgcn_rcpf(den);
+    const float e = __builtin_fmaf(-den, q, 1.0f);
+    rden = __builtin_fmaf(q, e, q);
+    const bool ok = ((((__float_as_uint(x) >> 23) & 0xFFu) - 32u) <= 190u) | (x == 0.0f);
+    if (__builtin_expect(!__all(ok), 0)) {
+        const float den_ieee = __builtin_sqrtf(x) + 1e-8f;
+        den = ok ? den : den_ieee;
+        rden = ok ? rden : 1.0f / den_ieee;
+    }
+}
+
 // Optimistic forms for the hot loops: the lean result is always computed and the validity of the
 // operand is ANDed into `ok` instead of branching; the caller tests `ok` once per stage and row
 // (one wave-uniform branch instead of one per call) and, when some lane saw an operand outside the

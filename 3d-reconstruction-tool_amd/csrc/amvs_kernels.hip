@@ -562,8 +562,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             const float mean2 = bv * INV_AREA;
             const float var2 = bvv * INV_AREA - mean2 * mean2;
             const float cov = brv * INV_AREA - m1 * mean2;
-            const float den = sqrt_rn(v1 * var2) + 1e-8f;
-            const float ncc = qdiv(cov, den, rcp_rn(den));
+            float den, rden;
+            ncc_denominator(v1 * var2, den, rden);
+            const float ncc = qdiv(cov, den, rden);
             const float cost = 1.0f - ncc;
             const bool oks = (okc >> s) & 1u;
             // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
