@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libamvs_oracle.so")
+_SO = os.environ.get("AMVS_ORACLE_SO") or os.path.join(_HERE, "libamvs_oracle.so")   # (sanitizer build: oracle/Makefile)
 _lib = None
 
 f32p = C.POINTER(C.c_float)
