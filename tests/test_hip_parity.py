@@ -264,6 +264,45 @@ def test_tiny_and_wide_source_sets_bit_exact(amvs_mod, shape, nviews, k, S):
             _eq(c, wc, "sweep confidence")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_wide_baselines_bit_exact(amvs_mod, seed):
+    """Random small shapes, patch sizes and source counts with wide baselines and a depth range that
+    throws many projections far outside the sources: the packed maps' zero border and origin clamp
+    (no tap masks) against the oracle's masked 4-tap sampler, PatchMatch and plane sweep."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(8, 80)), int(rng.integers(8, 150))
+    k = int(rng.choice([3, 5, 7]))
+    S = int(rng.integers(2, 5))
+    nviews = S + 1
+    sc = make_scene(nviews, H, W, seed=seed + 11, arc_step_deg=float(rng.uniform(12.0, 30.0)))
+    grays = [(np.round(g * 255.0).astype(np.uint8)).astype(np.float32) / np.float32(255.0) for g in sc.grays]
+    K = sc.camera.K.astype(np.float32)
+    ref = int(rng.integers(0, nviews))
+    srcs = [i for i in range(nviews) if i != ref]
+    dmin, dmax = np.float32(sc.depth_min * 0.2), np.float32(sc.depth_max * 4.0)
+    with amvs_mod.Engine(H, W, nviews, K) as eng:
+        for i in range(nviews):
+            eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "u8-pairs"
+        depth, normal, conf = eng.patchmatch([ref], [srcs], make_pm_params(k, 2, 3, dmin, dmax), 40 + seed)
+        ctx = oracle.ViewContext(K, grays[ref], sc.poses[ref].R, sc.poses[ref].t, [grays[i] for i in srcs],
+                                 [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k)
+        od, on, oc = ctx.patchmatch(2, 3, dmin, dmax, 40 + seed, ref)
+        tag = f"seed {seed}: {H}x{W} k{k} S{S}"
+        _eq(depth[0], od, tag + " depth")
+        _eq(conf[0], oc, tag + " confidence")
+        _eq(normal[0], on, tag + " normal")
+        if k in (5, 7):
+            planes = (1.0 / np.linspace(1 / dmax, 1 / dmin, 12)).astype(np.float32)
+            d, c = eng.plane_sweep(ref, srcs, planes, k, 0.8)
+            wd, wc = ctx.plane_sweep(planes, 0.8)
+            _eq(d, wd, tag + " sweep depth")
+            _eq(c, wc, tag + " sweep confidence")
+
+
 # --------------------------------------------------- full-size, size-independent ----
 def test_full_size_invariants(amvs_mod):
     """1920x1080 (BASELINE config 3 resolution): results do not depend on the strip height,
