@@ -166,10 +166,23 @@ def main():
     bounds = [(b * n_loc) // nb for b in range(nb + 1)]
     comm_stream = torch.cuda.Stream(device=dev)
 
+    # The exchange of a batch is also allowed to run under the NEXT step's sweeps: a step only waits
+    # for the exchanges of the step before it, and the closing fence for everything (so K timed steps
+    # expose one batch's exchange once, not K times).  The gather reads a packed copy, so the next
+    # sweep may overwrite the maps as soon as that copy has been made (comm_stream order).
+    in_flight = []
+
+    def drain(keep_last_step):
+        while len(in_flight) > (1 if keep_last_step else 0):
+            for w in in_flight.pop(0)[0]:
+                w.wait()
+
     def step():
         works, parts = [], []
         for b in range(nb):
             lo, hi = bounds[b], bounds[b + 1]
+            if world > 1:
+                stream.wait_stream(comm_stream)      # the previous packed copy of these rows is done
             eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[lo:hi].data_ptr(),
                                   normal[lo:hi].data_ptr(), conf[lo:hi].data_ptr())
             if world > 1:
@@ -187,15 +200,17 @@ def main():
                     works.append(dist.all_gather_into_tensor(recv, packed.contiguous(), async_op=True))
                     parts.append((lo, hi, recv, packed))
         eng.sync()
-        for w in works:
-            w.wait()
         if world > 1:
-            comm_stream.synchronize()
+            in_flight.append((works, parts))
+            drain(keep_last_step=True)
             gathered[0] = parts
 
     gathered = [None]
 
     def fence():
+        drain(keep_last_step=False)
+        if world > 1:
+            comm_stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
