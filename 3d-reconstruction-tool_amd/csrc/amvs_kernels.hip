@@ -364,7 +364,10 @@ AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *
 #define AMVS_WG_WAVES 1
 #endif
 
-template <int K, int S, bool U8>
+// MODE_T: MODE_PROP / MODE_REFINE are compiled as their own kernels (99 % of the launches: the mode
+// switches, the other modes' code and, for propagation steps, the whole RNG hash fall away at
+// compile time); -1 is the generic kernel, used for MODE_EVAL and MODE_CONF.
+template <int K, int S, bool U8, int MODE_T>
 __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm_step_kernel(const StepArgs a)
 {
     constexpr int HALF = K / 2;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     const int tx = rem - ty * a.tiles_x;
 
     const JobCP job = (JobCP)(a.jobs + job_id);
-    const int H = a.H, W = a.W, mode = a.mode;
+    const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
     const long long HW = (long long)H * W;
 
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
@@ -989,10 +992,18 @@ template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
-    if (a.pairs)
-        hipLaunchKernelGGL((pm_step_kernel<K, S, true>), dim3(nwg), dim3(AMVS_WAVE * AMVS_WG_WAVES), dyn_lds_bytes(), st, a);
-    else
-        hipLaunchKernelGGL((pm_step_kernel<K, S, false>), dim3(nwg), dim3(AMVS_WAVE * AMVS_WG_WAVES), dyn_lds_bytes(), st, a);
+    const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
+#define AMVS_LAUNCH_STEP(U8, M) hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, dyn_lds_bytes(), st, a)
+    if (a.pairs) {
+        if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(true, MODE_REFINE);
+        else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(true, MODE_PROP);
+        else AMVS_LAUNCH_STEP(true, -1);
+    } else {
+        if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(false, MODE_REFINE);
+        else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(false, MODE_PROP);
+        else AMVS_LAUNCH_STEP(false, -1);
+    }
+#undef AMVS_LAUNCH_STEP
     return hipGetLastError();
 }
 template <int K, int S>
@@ -1020,8 +1031,8 @@ static int step_occupancy_ks(bool u8)
 {
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
-    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true>, TPB, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false>, TPB, 0);
+    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true, MODE_REFINE>, TPB, 0)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false, MODE_REFINE>, TPB, 0);
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
