@@ -662,6 +662,69 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 #endif
 }
 
+// ------------------------------------------------------------------ split step (experiment) ---
+// Sampling stage of a sweep step as a kernel of its own: one thread per PX pixels of the reference
+// view (every pixel exactly once, no strip halo, no rings): candidate depth, back-projection, the S
+// projections / gathers / bilinear samples.  Writes the samples ([pixel][S] float32), the candidate
+// depth and the validity bits for a window / NCC / select kernel to stream.
+#ifdef AMVS_EXPERIMENT_SPLIT
+template <int S, bool U8, int PX>
+__global__ __launch_bounds__(256) void pm_sample_kernel(const StepArgs a, float *__restrict__ V,
+                                                        float *__restrict__ dcand, uint8_t *__restrict__ okmap)
+{
+    __shared__ float lut[256];
+    if (U8) {
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lut[threadIdx.x * 4 + j] = (float)(threadIdx.x * 4 + j) / 255.0f;
+        }
+        __syncthreads();
+    }
+    const int H = a.H, W = a.W, mode = a.mode;
+    const int bx_n = (W + 255) / 256, by_n = (H + PX - 1) / PX;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_job = bx_n * by_n;
+    const int job_id = t / per_job;
+    const int rem = t - job_id * per_job;
+    const int by = rem / bx_n, bx = rem - by * bx_n;
+    const JobCP job = (JobCP)(a.jobs + job_id);
+    const long long HW = (long long)H * W;
+    const float *__restrict__ d_in = a.d_in + job->slot * HW;
+    const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
+    const SampleConsts sc = make_sample_consts(H, W, mode == MODE_CONF ? 0.0f : (float)(a.TH),   // TH carries k/2 here
+                                               mode == MODE_CONF ? (float)W : (float)(W - a.TH),
+                                               mode == MODE_CONF ? (float)H : (float)(H - a.TH));
+    const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
+    const int x = bx * 256 + (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        const int y = by * PX + k;
+        const bool live = (x < W) & (y < H);
+        const bool inb = live & ((unsigned)(y + oy) < (unsigned)H) & ((unsigned)(x + ox) < (unsigned)W);
+        const int pix = y * W + x;
+        const float d_raw = d_in[inb ? pix + oy * W + ox : 0];
+        float dc = inb ? d_raw : a.depth_min;
+        if (mode == MODE_REFINE) {
+            const uint32_t h0 = pixel_hash((uint32_t)pix, key);
+            float d = dc + (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
+            d = d < a.depth_min ? a.depth_min : d;
+            dc = d > a.depth_max ? a.depth_max : d;
+        }
+        JobCP jr = reload(job);
+        const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, x, y, dc);
+        float v[S];
+        const unsigned okbits = sample_sources_checked<S, U8, false>(jr, a, sc, lut, Pw, live, v);
+        if (live) {
+            const long long o = job->slot * HW + pix;
+#pragma unroll
+            for (int s = 0; s < S; ++s) V[o * S + s] = v[s];
+            dcand[o] = dc;
+            okmap[o] = (uint8_t)okbits;
+        }
+    }
+}
+#endif
+
 // ------------------------------------------------------------------ plane sweep --
 // _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
 // count neighbours with NCC > thresh and z > 0.1; keep the first plane with the highest
@@ -1006,6 +1069,29 @@ static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 #undef AMVS_LAUNCH_STEP
     return hipGetLastError();
 }
+#ifdef AMVS_EXPERIMENT_SPLIT
+template <int K, int S>
+static hipError_t launch_sample_ks(const StepArgs &a0, hipStream_t st)
+{
+    // timing experiment: scratch outputs, never read
+    static float *V = nullptr, *dc = nullptr;
+    static uint8_t *ok = nullptr;
+    static long long cap = 0;
+    const long long n = (long long)a0.n_jobs * a0.H * a0.W;
+    if (n > cap) {
+        (void)hipMalloc(&V, sizeof(float) * n * S); (void)hipMalloc(&dc, sizeof(float) * n); (void)hipMalloc(&ok, n);
+        cap = n;
+    }
+    StepArgs a = a0;
+    a.TH = K / 2;
+    constexpr int PX = AMVS_EXPERIMENT_SPLIT;
+    const int nblk = a.n_jobs * ((a.W + 255) / 256) * ((a.H + PX - 1) / PX);
+    if (a.pairs) hipLaunchKernelGGL((pm_sample_kernel<S, true, PX>), dim3(nblk), dim3(256), 0, st, a, V, dc, ok);
+    else hipLaunchKernelGGL((pm_sample_kernel<S, false, PX>), dim3(nblk), dim3(256), 0, st, a, V, dc, ok);
+    return hipGetLastError();
+}
+#endif
+
 template <int K, int S>
 static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
 {
@@ -1055,6 +1141,9 @@ int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 {
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
+#ifdef AMVS_EXPERIMENT_SPLIT
+    if (K == 7 && S == 4) (void)launch_sample_ks<7, 4>(a, st);
+#endif
     switch (K) {
     case 3: AMVS_FOR_S(3, launch_step_ks, a, nblk, st)
     case 5: AMVS_FOR_S(5, launch_step_ks, a, nblk, st)
