@@ -217,8 +217,11 @@ int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requ
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
     const long long slots = (long long)c->n_cu * amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr);
-    // measured on MI355X (16 views 1080p, k=7, S=4): 16...27 rows within 1 %, 24 best, 32 -3 %, 40+ -15 %
-    const int cands[3] = {24, 16, 8};
+    // measured on MI355X (k=7, S=4): 16 views 1080p: 16...27 rows within 1 %, 24 best, 32 -3 %, 40+
+    // -15 %; 8 views 4K: 12...16 best, 24 -6 %; 1440p: 16 +1 % over 24 -- wider images want lower
+    // strips (the rows the resident waves touch at once scale with the width)
+    const int tall = c->W > 2048 ? 16 : 24;
+    const int cands[3] = {tall, 16, 8};
     for (int th : cands) {
         if (th > cap) continue;
         const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
