@@ -217,11 +217,14 @@ int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requ
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
     const long long slots = (long long)c->n_cu * amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr);
-    // measured on MI355X (k=7, S=4): 16 views 1080p: 16...27 rows within 1 %, 24 best, 32 -3 %, 40+
-    // -15 %; 8 views 4K: 12...16 best, 24 -6 %; 1440p: 16 +1 % over 24 -- wider images want lower
-    // strips (the rows the resident waves touch at once scale with the width)
-    const int tall = c->W > 2048 ? 16 : 24;
-    const int cands[3] = {tall, 16, 8};
+    // measured on MI355X (S=4, 16 views 1080p; best strip height per patch size): k=3: 10-12 rows,
+    // k=5: 14-18, k=7: 20-26 (32: -3 %, 40+: -15 %), k=9: 24-32, k=11: 32-40, i.e. about 4k-4: smaller
+    // patches leave more waves resident, and what matters is the set of source rows the resident
+    // waves touch at once.  For the same reason wider images want lower strips (8 views 4K, k=7:
+    // 12-16 rows best, 24: -6 %).
+    int tall = 4 * patch - 4 > 12 ? 4 * patch - 4 : 12;
+    if (c->W > 2048) tall = tall * 2 / 3 > 8 ? tall * 2 / 3 : 8;
+    const int cands[3] = {tall, tall < 16 ? tall : 16, 8};
     for (int th : cands) {
         if (th > cap) continue;
         const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
