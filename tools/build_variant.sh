@@ -6,7 +6,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/3d-reconstruction-tool_amd/csrc
 out=$root/build/variants; mkdir -p $out/obj_$name
-flags="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fvisibility=hidden -Wall -Wno-unused-result"
+flags="--offload-arch=${ARCH:-gfx950} -O3 -ffp-contract=off -fPIC -std=c++17 -fvisibility=hidden -Wall -Wno-unused-result"
 for f in amvs_kernels amvs_capi amvs_fusion amvs_knn; do
   if [ $f = amvs_kernels ] || [ ! -f $src/$f.o ]; then
     /opt/rocm/bin/hipcc $flags "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
@@ -15,6 +15,6 @@ for f in amvs_kernels amvs_capi amvs_fusion amvs_knn; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libamvs_$name.so $out/obj_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=${ARCH:-gfx950} -shared -fPIC -o $out/libamvs_$name.so $out/obj_$name/*.o
 rm -rf $out/obj_$name
 echo built $out/libamvs_$name.so
