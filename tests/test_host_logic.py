@@ -155,6 +155,16 @@ def test_prepare_view_identity_scale_and_gray_formula():
     assert np.array_equal(out["gray"], gray8.astype(np.float32) / np.float32(255.0))
     half = prepare_view(img, 0.5)
     assert half["shape"] == (6, 8) and half["gray"].dtype == np.float32
+    # all 2^24 colours through the 32-bit gray formula, and the thread pool keeps the order
+    from amvs.core.imageprep import prepare_views
+    cube = np.stack(np.meshgrid(*[np.arange(256, dtype=np.uint8)] * 3, indexing="ij"), axis=-1).reshape(4096, 4096, 3)
+    b, g, r = (cube[..., i].astype(np.int64) for i in range(3))
+    assert np.array_equal(prepare_view(cube, 1.0)["gray"],
+                          (((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.float32) / np.float32(255.0)))
+    imgs = [rng.integers(0, 256, (10, 14, 3), dtype=np.uint8) for _ in range(9)]
+    pooled, serial = prepare_views(imgs, 0.5), [prepare_view(im, 0.5) for im in imgs]
+    assert all(np.array_equal(p["gray"], q["gray"]) and np.array_equal(p["color"], q["color"])
+               for p, q in zip(pooled, serial))
 
 
 def test_save_ply_writes_the_reference_bytes(tmp_path):
