@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace amvs {
@@ -34,6 +36,8 @@ namespace {
 
 constexpr int KNN_KMAX = 32;
 constexpr int KNN_GMAX = 256;       // cells per axis (dense table of at most 2^24 cells)
+constexpr int KNN_SHELLS = 2;       // Chebyshev shells a query walks on one grid level
+constexpr int KNN_LEVELS = 3;       // grid levels (cell edge x2 per level) before the block scans
 
 struct Grid {
     double lo[3];
@@ -101,14 +105,21 @@ __device__ __forceinline__ double numpy_pairwise_sum(const double (&a)[KNN_KMAX]
     return res;
 }
 
+// One pass over one grid level: queries still `pending` walk at most `max_shells` shells; those
+// that cover their k-th distance write their mean and clear the flag, the others stay pending for
+// the next (coarser) level -- or, on the last level (`allow_scan`), scan every point.
 template <int K>
 __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict__ sorted, long long n, Grid gr,
                                                         const int *__restrict__ start,   // [cells + 1]
                                                         const int *__restrict__ origin,
+                                                        unsigned char *__restrict__ pending,   // by original index
+                                                        int max_shells, int allow_scan,
                                                         double *__restrict__ mean_out)
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
+    const int self = origin[q];
+    if (!pending[self]) return;
     const double qx = sorted[3 * q], qy = sorted[3 * q + 1], qz = sorted[3 * q + 2];
     const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
 
@@ -141,7 +152,9 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
         }
     };
 
-    const int rmax = max(max(gr.g[0], gr.g[1]), gr.g[2]);
+    const int gmax = max(max(gr.g[0], gr.g[1]), gr.g[2]);
+    const int rmax = min(max_shells, gmax);
+    bool done = false;
     for (int r = 0; r <= rmax; ++r) {
         const int x0 = max(cx - r, 0), x1 = min(cx + r, gr.g[0] - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, gr.g[1] - 1);
@@ -158,7 +171,33 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
             }
         // every unvisited point lies at least r*h away (slightly shrunk against rounding of the binning)
         const double reach = (double)r * gr.h * (1.0 - 1e-9);
-        if (worst <= reach * reach) break;
+        if (worst <= reach * reach) { done = true; break; }
+    }
+    if (!done && rmax >= gmax) done = true;        // every cell was visited
+    if (!done && !allow_scan) return;              // stays pending for the next level
+    if (!done) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
+        worst = __builtin_inf();
+        const int cells = gr.g[0] * gr.g[1] * gr.g[2];
+        const int total = start[cells];
+        for (int p = 0; p < total; ++p) {
+            const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
+                         dz = qz - sorted[3 * (long long)p + 2];
+            const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+            if (d2 < worst) {
+                bool hit_done = false;
+                double w = -1.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bool hit = !hit_done & (best[j] == worst);
+                    best[j] = hit ? d2 : best[j];
+                    hit_done |= hit;
+                    w = best[j] > w ? best[j] : w;
+                }
+                worst = w;
+            }
+        }
     }
 
     // ascending order, sqrt, drop the first (the query itself), numpy-order mean of the other K-1
@@ -172,15 +211,126 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
         }
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = sqrt(best[j]);
-    mean_out[origin[q]] = numpy_pairwise_sum<K - 1>(best, 1) / (double)(K - 1);
+    mean_out[self] = numpy_pairwise_sum<K - 1>(best, 1) / (double)(K - 1);
+    pending[self] = 0;
+}
+
+// Queries the grid levels left pending (isolated points: the outliers this statistic exists to
+// find): one 256-thread block per query scans ALL points -- coalesced, each thread keeps the K
+// smallest of its share -- and the block then extracts the K smallest overall, one per round, with a
+// (value, thread) arg-min reduction.  A single thread walking sparse cells takes ~85 ns per
+// candidate; this scan finishes a 277 k-point cloud in a few microseconds per query.
+template <int K>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const double *__restrict__ pts, long long n,
+                                                       const int *__restrict__ queries,       // original indices
+                                                       unsigned char *__restrict__ pending,
+                                                       double *__restrict__ mean_out)
+{
+    const int self = queries[blockIdx.x];
+    const double qx = pts[3 * (long long)self], qy = pts[3 * (long long)self + 1], qz = pts[3 * (long long)self + 2];
+    double best[KNN_KMAX];
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
+    double worst = __builtin_inf();
+    for (long long p = threadIdx.x; p < n; p += 256) {
+        const double dx = qx - pts[3 * p], dy = qy - pts[3 * p + 1], dz = qz - pts[3 * p + 2];
+        const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+        if (d2 < worst) {
+            bool hit_done = false;
+            double w = -1.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const bool hit = !hit_done & (best[j] == worst);
+                best[j] = hit ? d2 : best[j];
+                hit_done |= hit;
+                w = best[j] > w ? best[j] : w;
+            }
+            worst = w;
+        }
+    }
+    // own list ascending
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+#pragma unroll
+        for (int j = K - 1; j >= i; --j) {
+            const double a = best[j - 1], b = best[j];
+            best[j - 1] = a < b ? a : b;
+            best[j] = a < b ? b : a;
+        }
+    __shared__ double red_v[4];
+    __shared__ int red_t[4];
+    __shared__ double out[KNN_KMAX];
+    int head = 0;
+    for (int t = 0; t < K; ++t) {
+        // this thread's smallest unused value (static indexing: select over the list)
+        double v = __builtin_inf();
+#pragma unroll
+        for (int j = 0; j < K; ++j) v = (j == head) ? best[j] : v;
+        int who = threadIdx.x;
+        // wave arg-min, ties to the lower thread
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(v, off);
+            const int ow = __shfl_xor(who, off);
+            const bool take = (ov < v) | ((ov == v) & (ow < who));
+            v = take ? ov : v;
+            who = take ? ow : who;
+        }
+        if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = v; red_t[threadIdx.x >> 6] = who; }
+        __syncthreads();
+        double bv = red_v[0];
+        int bt = red_t[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const bool take = (red_v[w] < bv) | ((red_v[w] == bv) & (red_t[w] < bt));
+            bv = take ? red_v[w] : bv;
+            bt = take ? red_t[w] : bt;
+        }
+        if ((int)threadIdx.x == bt) head += 1;
+        if (threadIdx.x == 0) out[t] = bv;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double res[KNN_KMAX];
+#pragma unroll
+        for (int j = 0; j < K; ++j) res[j] = sqrt(out[j]);
+        mean_out[self] = numpy_pairwise_sum<K - 1>(res, 1) / (double)(K - 1);
+        pending[self] = 0;
+    }
+}
+
+template <int K>
+hipError_t launch_scan(const double *pts, long long n, const int *queries, int n_queries, unsigned char *pending,
+                       double *mean_out, hipStream_t st)
+{
+    hipLaunchKernelGGL((knn_scan_kernel<K>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, n, queries, pending, mean_out);
+    return hipGetLastError();
+}
+
+// number of cells holding at least one point
+__global__ __launch_bounds__(256) void knn_occupied_kernel(const int *__restrict__ count, long long cells,
+                                                           int *__restrict__ occupied)
+{
+    int local = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x)
+        local += count[i] > 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
+}
+
+__global__ __launch_bounds__(256) void knn_iota_kernel(int *__restrict__ v, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        v[i] = (int)i;
 }
 
 template <int K>
 hipError_t launch_query(const double *sorted, long long n, const Grid &gr, const int *start, const int *origin,
-                        double *mean_out, hipStream_t st)
+                        unsigned char *pending, int max_shells, int allow_scan, double *mean_out, hipStream_t st)
 {
     hipLaunchKernelGGL((knn_query_kernel<K>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, sorted, n, gr,
-                       start, origin, mean_out);
+                       start, origin, pending, max_shells, allow_scan, mean_out);
     return hipGetLastError();
 }
 
@@ -191,32 +341,47 @@ bool knn_supported(int k) { return k == 8 || k == 10 || k == 16 || k == 20 || k 
 // points: host [n][3] float64; mean_out: host [n].  Needs n >= k.
 hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st)
 {
-    // bounding box and cell edge: about 8 points per cell if the points filled the box, refined below
-    // from the occupancy actually found (reconstructed clouds are surfaces, not volumes)
-    Grid gr{};
-    double hi[3];
-    for (int a = 0; a < 3; ++a) { gr.lo[a] = points[a]; hi[a] = points[a]; }
-    for (long long i = 1; i < n; ++i)
+    // The grid spans the 1st .. 99th percentile of every axis (estimated on a strided sample); points
+    // outside are binned into the border cells (per-axis clamping only under-estimates coordinate
+    // differences, so the shell bound stays valid).  A handful of far outliers -- what this statistic
+    // is computed to find -- would otherwise stretch the box until the body of the cloud falls into a
+    // few crowded cells.
+    double lo[3], hi[3];
+    {
+        const long long stride = std::max<long long>(1, n / 65536);
+        std::vector<double> axis;
+        axis.reserve((size_t)(n / stride + 1));
         for (int a = 0; a < 3; ++a) {
-            gr.lo[a] = std::min(gr.lo[a], points[3 * i + a]);
-            hi[a] = std::max(hi[a], points[3 * i + a]);
+            axis.clear();
+            for (long long i = 0; i < n; i += stride) axis.push_back(points[3 * i + a]);
+            const size_t m = axis.size(), lo_k = (m - 1) / 100, hi_k = (m - 1) - lo_k;
+            std::nth_element(axis.begin(), axis.begin() + lo_k, axis.end());
+            lo[a] = axis[lo_k];
+            std::nth_element(axis.begin(), axis.begin() + hi_k, axis.end());
+            hi[a] = axis[hi_k];
         }
+    }
     double ext[3], emax = 0.0;
-    for (int a = 0; a < 3; ++a) { ext[a] = hi[a] - gr.lo[a]; emax = std::max(emax, ext[a]); }
+    for (int a = 0; a < 3; ++a) { ext[a] = hi[a] - lo[a]; emax = std::max(emax, ext[a]); }
     if (!(emax > 0.0) || !std::isfinite(emax)) emax = 1.0;
     double vol = 1.0;
     for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], emax * 1e-3);
+    // about 8 points per cell if the points filled the box, refined below from the occupancy actually
+    // found (reconstructed clouds are surfaces plus diffuse noise, not volumes)
     double h = std::cbrt(vol * 8.0 / (double)n);
-    const double h_min = emax / (KNN_GMAX - 2);      // keeps every cell index below KNN_GMAX without clamping
+    const double h_min = emax / (KNN_GMAX - 2);      // keeps every in-box cell index below KNN_GMAX
     h = std::max(h, h_min);
 
     double *d_pts = nullptr, *d_sorted = nullptr, *d_mean = nullptr;
     int *d_cell = nullptr, *d_count = nullptr, *d_start = nullptr, *d_origin = nullptr;
+    unsigned char *d_pending = nullptr;
+    int *d_occ = nullptr;
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    long long table_cap = 0;
     auto cleanup = [&]() {
         for (void *p : {(void *)d_pts, (void *)d_sorted, (void *)d_mean, (void *)d_cell, (void *)d_count,
-                        (void *)d_start, (void *)d_origin, d_tmp})
+                        (void *)d_start, (void *)d_origin, (void *)d_pending, (void *)d_occ, d_tmp})
             if (p) (void)hipFree(p);
     };
 #define KCHK_C(call)                                                   \
@@ -229,56 +394,154 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     KCHK_C(hipMalloc(&d_mean, sizeof(double) * n));
     KCHK_C(hipMalloc(&d_cell, sizeof(int) * n));
     KCHK_C(hipMalloc(&d_origin, sizeof(int) * n));
+    KCHK_C(hipMalloc(&d_pending, (size_t)n));
+    KCHK_C(hipMalloc(&d_occ, sizeof(int)));
     KCHK_C(hipMemcpyAsync(d_pts, points, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    KCHK_C(hipMemsetAsync(d_pending, 1, (size_t)n, st));
 
     const int bx = (int)std::min<long long>((n + 255) / 256, 4096);
+    Grid gr{};
+    for (int a = 0; a < 3; ++a) gr.lo[a] = lo[a];
     long long cells = 0;
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        gr.h = h; gr.inv_h = 1.0 / h;
-        for (int a = 0; a < 3; ++a) gr.g[a] = std::max(1, std::min(KNN_GMAX, (int)std::floor(ext[a] / h) + 1));
+    // bins the points for edge `edge` (count + exclusive scan); returns points per occupied cell
+    auto bin = [&](double edge, double &per_cell) -> hipError_t {
+        gr.h = edge; gr.inv_h = 1.0 / edge;
+        for (int a = 0; a < 3; ++a) gr.g[a] = std::max(1, std::min(KNN_GMAX, (int)std::floor(ext[a] / edge) + 1));
         cells = (long long)gr.g[0] * gr.g[1] * gr.g[2];
-        if (d_count) { (void)hipFree(d_count); d_count = nullptr; }
-        if (d_start) { (void)hipFree(d_start); d_start = nullptr; }
-        KCHK_C(hipMalloc(&d_count, sizeof(int) * (cells + 1)));
-        KCHK_C(hipMalloc(&d_start, sizeof(int) * (cells + 1)));
-        KCHK_C(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));
+        if (cells + 1 > table_cap) {
+            if (d_count) (void)hipFree(d_count);
+            if (d_start) (void)hipFree(d_start);
+            d_count = d_start = nullptr;
+            KCHK(hipMalloc(&d_count, sizeof(int) * (cells + 1)));
+            KCHK(hipMalloc(&d_start, sizeof(int) * (cells + 1)));
+            table_cap = cells + 1;
+        }
+        KCHK(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));
         hipLaunchKernelGGL(knn_count_kernel, dim3(bx), dim3(256), 0, st, d_pts, n, gr, d_cell, d_count);
-        KCHK_C(hipGetLastError());
-        // occupancy of the occupied cells decides whether the edge fits the data
+        KCHK(hipGetLastError());
         size_t need = 0;
-        KCHK_C(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_count, d_start, (int)(cells + 1), st));
+        KCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_count, d_start, (int)(cells + 1), st));
         if (need > tmp_bytes) {
             if (d_tmp) (void)hipFree(d_tmp);
             d_tmp = nullptr;
-            KCHK_C(hipMalloc(&d_tmp, need));
+            KCHK(hipMalloc(&d_tmp, need));
             tmp_bytes = need;
         }
-        KCHK_C(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_count, d_start, (int)(cells + 1), st));
-        std::vector<int> cnt(cells);
-        KCHK_C(hipMemcpyAsync(cnt.data(), d_count, sizeof(int) * cells, hipMemcpyDeviceToHost, st));
-        KCHK_C(hipStreamSynchronize(st));
-        long long occupied = 0;
-        for (long long c = 0; c < cells; ++c) occupied += cnt[c] > 0;
-        const double per_cell = (double)n / (double)std::max<long long>(occupied, 1);
+        KCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_count, d_start, (int)(cells + 1), st));
+        if (per_cell >= 0.0) {
+            KCHK(hipMemsetAsync(d_occ, 0, sizeof(int), st));
+            const int cb = (int)std::min<long long>((cells + 255) / 256, 2048);
+            hipLaunchKernelGGL(knn_occupied_kernel, dim3(cb), dim3(256), 0, st, d_count, cells, d_occ);
+            KCHK(hipGetLastError());
+            int occupied = 0;
+            KCHK(hipMemcpyAsync(&occupied, d_occ, sizeof(int), hipMemcpyDeviceToHost, st));
+            KCHK(hipStreamSynchronize(st));
+            per_cell = (double)n / (double)std::max(occupied, 1);
+        }
+        return hipSuccess;
+    };
+    auto query = [&](int max_shells, int allow_scan) -> hipError_t {
+        KCHK(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));     // reused as the placement cursor
+        hipLaunchKernelGGL(knn_place_kernel, dim3(bx), dim3(256), 0, st, d_pts, n, d_cell, d_start, d_count,
+                           d_sorted, d_origin);
+        KCHK(hipGetLastError());
+        switch (k) {
+        case 8: return launch_query<8>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        case 10: return launch_query<10>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        case 16: return launch_query<16>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        case 20: return launch_query<20>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        case 32: return launch_query<32>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        default: return hipErrorInvalidValue;
+        }
+    };
+
+    // level 0: edge fitted to the occupancy of the occupied cells (3 .. 24 points)
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        double per_cell = 0.0;
+        KCHK_C(bin(h, per_cell));
         const bool at_limit = gr.g[0] == KNN_GMAX || gr.g[1] == KNN_GMAX || gr.g[2] == KNN_GMAX;
         if (per_cell > 24.0 && !at_limit && h > h_min) { h = std::max(h * 0.5, h_min); continue; }
         if (per_cell < 3.0 && cells > 1) { h *= 2.0; continue; }
         break;
     }
-    KCHK_C(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));     // reused as the placement cursor
-    hipLaunchKernelGGL(knn_place_kernel, dim3(bx), dim3(256), 0, st, d_pts, n, d_cell, d_start, d_count, d_sorted,
-                       d_origin);
-    KCHK_C(hipGetLastError());
-    hipError_t e = hipErrorInvalidValue;
-    switch (k) {
-    case 8: e = launch_query<8>(d_sorted, n, gr, d_start, d_origin, d_mean, st); break;
-    case 10: e = launch_query<10>(d_sorted, n, gr, d_start, d_origin, d_mean, st); break;
-    case 16: e = launch_query<16>(d_sorted, n, gr, d_start, d_origin, d_mean, st); break;
-    case 20: e = launch_query<20>(d_sorted, n, gr, d_start, d_origin, d_mean, st); break;
-    case 32: e = launch_query<32>(d_sorted, n, gr, d_start, d_origin, d_mean, st); break;
-    default: break;
+    // coarser levels (edge x2 each) pick up the queries whose neighbourhood is sparser than two
+    // shells of the level before; the last level may scan
+    const bool debug = std::getenv("AMVS_KNN_DEBUG") != nullptr;
+    int *d_iota = nullptr, *d_queries = nullptr, *d_nsel = nullptr;
+    auto cleanup2 = [&]() {
+        for (void *p : {(void *)d_iota, (void *)d_queries, (void *)d_nsel})
+            if (p) (void)hipFree(p);
+        d_iota = d_queries = d_nsel = nullptr;
+    };
+#define KCHK_D(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) { cleanup2(); cleanup(); return e_; }    \
+    } while (0)
+    KCHK_D(hipMalloc(&d_iota, sizeof(int) * n));
+    KCHK_D(hipMalloc(&d_queries, sizeof(int) * n));
+    KCHK_D(hipMalloc(&d_nsel, sizeof(int)));
+    hipLaunchKernelGGL(knn_iota_kernel, dim3(bx), dim3(256), 0, st, d_iota, n);
+    KCHK_D(hipGetLastError());
+    // the still-pending queries, compacted (and counted) after every level
+    auto pending_list = [&](int &count) -> hipError_t {
+        size_t need = 0;
+        KCHK(hipcub::DeviceSelect::Flagged(nullptr, need, d_iota, d_pending, d_queries, d_nsel, (int)n, st));
+        if (need > tmp_bytes) {
+            if (d_tmp) (void)hipFree(d_tmp);
+            d_tmp = nullptr;
+            KCHK(hipMalloc(&d_tmp, need));
+            tmp_bytes = need;
+        }
+        KCHK(hipcub::DeviceSelect::Flagged(d_tmp, tmp_bytes, d_iota, d_pending, d_queries, d_nsel, (int)n, st));
+        KCHK(hipMemcpyAsync(&count, d_nsel, sizeof(int), hipMemcpyDeviceToHost, st));
+        return hipStreamSynchronize(st);
+    };
+    int left = (int)n;
+    for (int level = 0; level < KNN_LEVELS && left > 0; ++level) {
+        hipEvent_t e0, e1;
+        if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+        const bool whole_grid = cells == 1;        // a one-cell grid is a scan already
+        KCHK_D(query(KNN_SHELLS, 0));
+        KCHK_D(pending_list(left));
+        if (debug) {
+            (void)hipEventRecord(e1, st);
+            (void)hipStreamSynchronize(st);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            std::fprintf(stderr, "knn level %d: h %.4g grid %dx%dx%d  %.2f ms, %d of %lld still pending\n", level, gr.h,
+                         gr.g[0], gr.g[1], gr.g[2], ms, left, n);
+        }
+        if (whole_grid || left == 0 || level == KNN_LEVELS - 1) break;
+        // the next level only pays when many queries are left; a few thousand go straight to the scans
+        if ((long long)left * 64 < n) break;
+        h *= 2.0;
+        double unused = -1.0;
+        KCHK_D(bin(h, unused));
     }
-    KCHK_C(e);
+    if (left > 0) {
+        hipEvent_t e0, e1;
+        if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+        hipError_t e = hipErrorInvalidValue;
+        switch (k) {
+        case 8: e = launch_scan<8>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
+        case 10: e = launch_scan<10>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
+        case 16: e = launch_scan<16>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
+        case 20: e = launch_scan<20>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
+        case 32: e = launch_scan<32>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
+        default: break;
+        }
+        KCHK_D(e);
+        if (debug) {
+            (void)hipEventRecord(e1, st);
+            (void)hipStreamSynchronize(st);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            std::fprintf(stderr, "knn block scans: %d queries  %.2f ms\n", left, ms);
+        }
+    }
+    cleanup2();
+#undef KCHK_D
     KCHK_C(hipMemcpyAsync(mean_out, d_mean, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     KCHK_C(hipStreamSynchronize(st));
     cleanup();
