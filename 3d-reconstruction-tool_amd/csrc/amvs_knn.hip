@@ -10,9 +10,11 @@
 //   * np.mean over the remaining k-1 values is numpy's pairwise summation: eight accumulators over
 //     blocks of eight, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the tail added in order.
 // The values do not depend on how ties are broken, so any exact k-nearest search gives them.  The
-// search here is a uniform grid: points are binned into cells of edge h (counting sort), a thread
-// per point visits the cells of growing Chebyshev shells around its own cell and stops after shell
-// r once its k-th smallest squared distance is <= (r*h)^2 (everything not yet visited is farther).
+// search here: points are binned into a uniform grid over the 1st-99th percentile box (counting
+// sort, cell edge h fitted to the occupancy); a thread per point visits the cells of Chebyshev shells
+// 0..2 around its own cell and is done after shell r once its k-th smallest squared distance is
+// <= (r*h)^2 (everything not yet visited is farther); queries left pending repeat on coarser grids
+// (edge x2), and the remainder -- isolated points -- is answered by one block each scanning all points.
 #include "amvs_kernels.h"
 
 #include <hipcub/hipcub.hpp>
