@@ -514,6 +514,24 @@ def test_stereo_outlier_filter_device_equals_host(eng_a, amvs_mod):
     assert np.array_equal(dev_p, host_p) and np.array_equal(dev_c, host_c)
 
 
+def test_stereo_reconstruct_device_filter_equals_sklearn_filter(amvs_mod):
+    """DenseStereoReconstructor.reconstruct end to end on the GPU: the cloud with the device
+    neighbour search equals the cloud with the reference's scikit-learn search, point for point."""
+    pytest.importorskip("sklearn.neighbors")
+    from amvs.core.dense_stereo import DenseStereoReconstructor
+    from amvs.synthetic import make_scene
+    sc = make_scene(5, 120, 160, seed=21)
+    images = [{"image": np.ascontiguousarray(c[:, :, ::-1])} for c in sc.colors]
+    poses = dict(sc.poses) if isinstance(sc.poses, dict) else {i: p for i, p in enumerate(sc.poses)}
+    clouds = []
+    for device_filter in (True, False):
+        rec = DenseStereoReconstructor(sc.camera, scale=1.0, device_filter=device_filter)
+        clouds.append(rec.reconstruct(images, poses, max_pairs=30))
+    (p_dev, c_dev), (p_host, c_host) = clouds
+    assert len(p_host) > 100
+    assert np.array_equal(p_dev, p_host) and np.array_equal(c_dev, c_host)
+
+
 def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
     d = scene_a.gt_depth[2]
