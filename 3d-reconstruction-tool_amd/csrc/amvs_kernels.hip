@@ -369,6 +369,9 @@ AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *
 #ifndef AMVS_WG_SYNC_ROWS
 #define AMVS_WG_SYNC_ROWS 8
 #endif
+#if defined(AMVS_HSUM_LDS) && AMVS_WG_WAVES > 1
+#error "the LDS horizontal-sum variant keeps one exchange buffer per workgroup: build it with -DAMVS_WG_WAVES=1"
+#endif
 
 // MODE_T: MODE_PROP / MODE_REFINE are compiled as their own kernels (99 % of the launches: the mode
 // switches, the other modes' code and, for propagation steps, the whole RNG hash fall away at
@@ -1133,7 +1136,7 @@ static int step_occupancy_ks(bool u8)
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
-// resident single-wave blocks per CU of the sweep kernel (register-limited)
+// resident waves per CU of the sweep kernel (register-limited)
 int step_waves_per_cu(int K, int S, bool u8)
 {
     switch (K) {
