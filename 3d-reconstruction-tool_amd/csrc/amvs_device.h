@@ -348,10 +348,6 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
                                  bool &ok)
 {
     const int H = c.H, W = c.W;
-#ifdef AMVS_ABL_NOPROJ      // timing-only: no projection arithmetic
-    float z = Pw.z + ts[2];
-    float u = Pw.x + Rs[0], v = Pw.y + Rs[1];
-#else
     float p0 = __builtin_fmaf(Pw.z, Rs[2], __builtin_fmaf(Pw.y, Rs[1], Pw.x * Rs[0])) + ts[0];
     float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
     float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
@@ -360,17 +356,12 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
     float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];
-#endif
     // non-short-circuit '&': '&&' makes hipcc emit a branch per source here
     valid = (z > 0.1f) & (u >= c.lo) & (u < c.hix) & (v >= c.lo) & (v < c.hiy);
-#ifdef AMVS_ABL_NOROUNDTRIP  // timing-only: sample at (u,v) directly
-    float ux = u, uy = v;
-#else
     float gx = qdiv(2.0f * u, c.fw, c.rfw) - 1.0f;
     float gy = qdiv(2.0f * v, c.fh, c.rfh) - 1.0f;
     float ux = (gx + 1.0f) * c.hw2;
     float uy = (gy + 1.0f) * c.hh2;
-#endif
     float x0 = __builtin_floorf(ux), y0 = __builtin_floorf(uy);
     float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
     float wx1 = ux - x0, wx0 = x1 - ux, wy1 = uy - y0, wy0 = y1 - uy;
@@ -433,11 +424,7 @@ AMVS_DEV TapRaw<U8> sample_load(unsigned long long img, const TapGeom<U8> &g, in
 {
     TapRaw<U8> r;
     if constexpr (U8) {
-#ifdef AMVS_ABLATE_L1_GATHER   // timing-only experiment: every gather hits a 2 KB window
-        r.w = load_pair_word(img, g.off & 1023, pitch);
-#else
         r.w = load_pair_word(img, g.off, pitch);
-#endif
     } else {
         const GlobalFloats f = (GlobalFloats)img;
         r.t00 = f[g.o00]; r.t01 = f[g.o01]; r.t10 = f[g.o10]; r.t11 = f[g.o11];

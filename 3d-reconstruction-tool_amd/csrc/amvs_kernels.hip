@@ -20,7 +20,6 @@
 #include "amvs_kernels.h"
 #include "amvs_device.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace amvs {
@@ -39,17 +38,8 @@ AMVS_DEV JobCP reload(JobCP p)
     return p;
 }
 
-// timing-only ablations (results are wrong when any is defined)
-#ifdef AMVS_ABL_LOCALSTREAM
-#define AMVS_SIDX(i) ((i) & 1023)
-#else
-#define AMVS_SIDX(i) (i)
-#endif
-
 // (Non-temporal hints on the streaming state were measured without effect on MI355X -- 31.8 vs 31.7
 // G px-hyp/s -- and are not used.)
-#define AMVS_LDS_STREAM(p) (*(p))
-#define AMVS_ST_STREAM(p, v) (*(p) = (v))
 
 // contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
 AMVS_DEV int xcd_remap(int bid, int nblk)
@@ -58,27 +48,6 @@ AMVS_DEV int xcd_remap(int bid, int nblk)
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
-
-// AMVS_TIMERS (measurement build only): per-wave cycle totals of the phases of a row, printed by a
-// few sampled waves.  ph 0: state loads + wait, 1: geometry, 2: gather wait, 3: decode + ring push,
-// 4: window sums + NCC (includes the wait for the old cost/depth), 5: select + stores.
-#ifdef AMVS_TIMERS
-struct Timers { unsigned long long acc[8]; unsigned long long last; };
-AMVS_DEV void tmark(Timers &tm, int ph, bool drain)
-{
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long now = __builtin_amdgcn_s_memtime();
-    tm.acc[ph] += now - tm.last;
-    tm.last = now;
-}
-#define AMVS_TMARK(ph, drain) tmark(tm, ph, drain)
-#define AMVS_TM_PARAM , Timers &tm
-#define AMVS_TM_ARG , tm
-#else
-#define AMVS_TMARK(ph, drain)
-#define AMVS_TM_PARAM
-#define AMVS_TM_ARG
-#endif
 
 // Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
 // (1) or after every operation / source (0, measured 2 % faster there).  The plane sweep always
@@ -117,7 +86,7 @@ AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
 // source); SRC_CHECK = false leaves the test to the caller (one branch per row).
 template <int S, bool U8, bool LEAN, bool SRC_CHECK>
 AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                 Vec3 Pw, bool live, float (&v)[S], bool &ok AMVS_TM_PARAM)
+                                 Vec3 Pw, bool live, float (&v)[S], bool &ok)
 {
     unsigned okbits = 0u;
     JobCP jr = job;
@@ -146,10 +115,8 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
         okbits |= valid ? (1u << s) : 0u;
         tr[s] = sample_load<U8>(c.img, tg[s], sc.W + 2 * AMVS_PAIR_BORDER);
     }
-    AMVS_TMARK(1, false);
 #pragma unroll
     for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
-    AMVS_TMARK(2, false);
     return okbits;
 }
 
@@ -157,13 +124,13 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
 // projection depth left the range the lean reciprocal is verified for (amvs_device.h).
 template <int S, bool U8, bool ROW_CHECK>
 AMVS_DEV unsigned sample_sources_checked(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                         Vec3 Pw, bool live, float (&v)[S] AMVS_TM_PARAM)
+                                         Vec3 Pw, bool live, float (&v)[S])
 {
     bool ok = true;
-    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true>(job, a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
-    unsigned okbits = sample_sources<S, U8, true, false>(job, a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
+    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true>(job, a, sc, lut, Pw, live, v, ok);
+    unsigned okbits = sample_sources<S, U8, true, false>(job, a, sc, lut, Pw, live, v, ok);
     if (__builtin_expect(!__all(ok), 0))
-        okbits = sample_sources<S, U8, false, false>(reload(job), a, sc, lut, Pw, live, v, ok AMVS_TM_ARG);
+        okbits = sample_sources<S, U8, false, false>(reload(job), a, sc, lut, Pw, live, v, ok);
     return okbits;
 }
 
@@ -276,12 +243,10 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
     float acc[NV4 * 4];
 #pragma unroll
     for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
-#ifndef AMVS_ABL_NOHSUM      // timing-only: no horizontal pass
 #pragma unroll
     for (int j = 1; j < K; ++j)
 #pragma unroll
         for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
-#endif
 #else
     float4 *mine = hbuf + lane * NV4;
 #pragma unroll
@@ -464,10 +429,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     // VGPRs, requesting the next row's depth / ref gray a row ahead measured nothing.
     const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
     const int noff = oy * W + ox;
-#ifdef AMVS_TIMERS
-    Timers tm = {};
-    tm.last = __builtin_amdgcn_s_memtime();
-#endif
 
     for (int r = 0; r < rows; ++r) {
 #if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
@@ -479,21 +440,17 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const float d_raw = d_in[AMVS_SIDX(inb ? pix + noff : 0)];       // re-read by neighbours: cached
+        const float d_raw = d_in[inb ? pix + noff : 0];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
-        const float r_raw = U8 ? lut[AMVS_REF_CODE(AMVS_SIDX(live ? pix + PADW * yr : 0)) & 0xFFu]
-                               : AMVS_LDS_STREAM(&ref[AMVS_SIDX(live ? pix : 0)]);
+        const float r_raw = U8 ? lut[AMVS_REF_CODE(live ? pix + PADW * yr : 0) & 0xFFu]
+                               : ref[live ? pix : 0];
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
         float dc = inb ? d_raw : a.depth_min;
         // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
-#ifdef AMVS_ABL_NOHASH       // timing-only
-        const uint32_t h0 = (uint32_t)pix * 2654435761u;
-#else
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
-#endif
         {
             float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
             float d = dc + delta;
@@ -506,8 +463,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
 
         float v[S];
-        AMVS_TMARK(0, true);
-        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
+        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING>(jr, a, sc, lut, Pw, live, v);
 
         // ---- push into the vertical rings ----
         ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
@@ -516,7 +472,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 #pragma unroll
         for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
         hist_h0[HALF] = h0;
-        AMVS_TMARK(3, false);
 
         if (r < 2 * HALF) continue;
 
@@ -524,8 +479,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const int yc = yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
-        const int pc = AMVS_SIDX(outl ? yc * W + xc : 0);
-        const float oldd = d_in[pc], oldc = AMVS_LDS_STREAM(&cost_io[pc]);
+        const int pc = outl ? yc * W + xc : 0;
+        const float oldd = d_in[pc], oldc = cost_io[pc];
         // the centre pixel was sampled by lane+HALF, HALF rows ago
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);     // low S bits: row r-HALF
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
@@ -549,13 +504,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
                 const float mean2 = bv * INV_AREA;
                 const float var2 = bvv * INV_AREA - mean2 * mean2;
                 const float cov = brv * INV_AREA - m1 * mean2;
-#ifdef AMVS_ABL_NONCC        // timing-only: no sqrt / divide
-                const float cost = cov + v1 * var2;
-#else
                 const float den = sqrt_t<LEAN>(v1 * var2, ok) + 1e-8f;
                 const float ncc = qdiv(cov, den, rcp_t<LEAN>(den, ok));
                 const float cost = 1.0f - ncc;
-#endif
                 const bool oks = (okc >> s) & 1u;
                 // confidence: consistent = valid & (1 - cost > 0.6)   (mvs_patchmatch.py:530-532)
                 const float ncc2 = 1.0f - cost;
@@ -592,14 +543,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             cnt = hit ? cnt + 1.0f : cnt;
         }
 #endif
-        AMVS_TMARK(4, true);
         // lanes that own an output pixel; control flow below stays wave-uniform (the refinement
         // queue needs every lane), so the stores are predicated instead of skipped
-#ifdef AMVS_ABL_NOSTORE
-        const bool act = outl & (cnt > 1e30f);
-#else
         const bool act = outl;
-#endif
 
         if (mode == MODE_CONF) {
             if (act) aux[pc] = cnt;
@@ -632,17 +578,17 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
             const bool zero = better & !inb_c;
             if (act) {
-                AMVS_ST_STREAM(&d_out[pc], better ? (inb_c ? nb_d : a.depth_min) : oldd);
-                AMVS_ST_STREAM(&n_out[3 * pc], zero ? 0.0f : t0);
-                AMVS_ST_STREAM(&n_out[3 * pc + 1], zero ? 0.0f : t1);
-                AMVS_ST_STREAM(&n_out[3 * pc + 2], zero ? 0.0f : t2);
+                d_out[pc] = better ? (inb_c ? nb_d : a.depth_min) : oldd;
+                n_out[3 * pc] = zero ? 0.0f : t0;
+                n_out[3 * pc + 1] = zero ? 0.0f : t1;
+                n_out[3 * pc + 2] = zero ? 0.0f : t2;
             }
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            if (act) AMVS_ST_STREAM(&d_out[pc], better ? d : oldd);
+            if (act) d_out[pc] = better ? d : oldd;
             // The winners' normals (normalize(normal + randn*range), mvs_patchmatch.py:475-476) are
             // not updated here: a row has ~3 winners among its 58 pixels, yet the ~150-instruction
             // update would run for the whole wave on almost every row.  Winners are queued in LDS
@@ -660,7 +606,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
                 }
             }
         }
-        AMVS_TMARK(5, false);
     }
     if (mode == MODE_REFINE) {
         while (q_tail - q_head > 0) {
@@ -669,11 +614,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             q_head += n;
         }
     }
-#ifdef AMVS_TIMERS
-    if ((blockIdx.x % 4099) == 7 && lane == 0 && (a.draw % 10 == 1 || a.draw % 10 == 5))
-        printf("TM mode %d draw %u rows %d ph %llu %llu %llu %llu %llu %llu\n", mode, a.draw, rows, tm.acc[0], tm.acc[1],
-               tm.acc[2], tm.acc[3], tm.acc[4], tm.acc[5]);
-#endif
 }
 
 // ------------------------------------------------------------------ split step (experiment) ---
@@ -681,63 +621,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 // view (every pixel exactly once, no strip halo, no rings): candidate depth, back-projection, the S
 // projections / gathers / bilinear samples.  Writes the samples ([pixel][S] float32), the candidate
 // depth and the validity bits for a window / NCC / select kernel to stream.
-#ifdef AMVS_EXPERIMENT_SPLIT
-template <int S, bool U8, int PX>
-__global__ __launch_bounds__(256) void pm_sample_kernel(const StepArgs a, float *__restrict__ V,
-                                                        float *__restrict__ dcand, uint8_t *__restrict__ okmap)
-{
-    __shared__ float lut[256];
-    if (U8) {
-        if (threadIdx.x < 64) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lut[threadIdx.x * 4 + j] = (float)(threadIdx.x * 4 + j) / 255.0f;
-        }
-        __syncthreads();
-    }
-    const int H = a.H, W = a.W, mode = a.mode;
-    const int bx_n = (W + 255) / 256, by_n = (H + PX - 1) / PX;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_job = bx_n * by_n;
-    const int job_id = t / per_job;
-    const int rem = t - job_id * per_job;
-    const int by = rem / bx_n, bx = rem - by * bx_n;
-    const JobCP job = (JobCP)(a.jobs + job_id);
-    const long long HW = (long long)H * W;
-    const float *__restrict__ d_in = a.d_in + job->slot * HW;
-    const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
-    const SampleConsts sc = make_sample_consts(H, W, mode == MODE_CONF ? 0.0f : (float)(a.TH),   // TH carries k/2 here
-                                               mode == MODE_CONF ? (float)W : (float)(W - a.TH),
-                                               mode == MODE_CONF ? (float)H : (float)(H - a.TH));
-    const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
-    const int x = bx * 256 + (int)threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < PX; ++k) {
-        const int y = by * PX + k;
-        const bool live = (x < W) & (y < H);
-        const bool inb = live & ((unsigned)(y + oy) < (unsigned)H) & ((unsigned)(x + ox) < (unsigned)W);
-        const int pix = y * W + x;
-        const float d_raw = d_in[inb ? pix + oy * W + ox : 0];
-        float dc = inb ? d_raw : a.depth_min;
-        if (mode == MODE_REFINE) {
-            const uint32_t h0 = pixel_hash((uint32_t)pix, key);
-            float d = dc + (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
-            d = d < a.depth_min ? a.depth_min : d;
-            dc = d > a.depth_max ? a.depth_max : d;
-        }
-        JobCP jr = reload(job);
-        const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, x, y, dc);
-        float v[S];
-        const unsigned okbits = sample_sources_checked<S, U8, false>(jr, a, sc, lut, Pw, live, v);
-        if (live) {
-            const long long o = job->slot * HW + pix;
-#pragma unroll
-            for (int s = 0; s < S; ++s) V[o * S + s] = v[s];
-            dcand[o] = dc;
-            okmap[o] = (uint8_t)okbits;
-        }
-    }
-}
-#endif
 
 // ------------------------------------------------------------------ plane sweep --
 // _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
@@ -802,9 +685,6 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
         }
         int wslot = 0;
-#ifdef AMVS_TIMERS
-        Timers tm = {};
-#endif
 
         for (int r = 0; r < rows; ++r) {
             const int yr = y0 - HALF + r;
@@ -815,7 +695,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             JobCP jr = reload(job);
             const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
             float v[S];
-            const unsigned okbits = sample_sources_checked<S, U8, true>(jr, a, sc, lut, Pw, live, v AMVS_TM_ARG);
+            const unsigned okbits = sample_sources_checked<S, U8, true>(jr, a, sc, lut, Pw, live, v);
             ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
             wslot = wslot + 1 == K ? 0 : wslot + 1;
             hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
@@ -1057,20 +937,12 @@ hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st)
 }
 
 // ------------------------------------------------------------------ dispatch -----
-// AMVS_DYN_LDS=<bytes>: experiment knob -- extra dynamic LDS per block caps the resident waves per
-// CU (160 KiB / bytes), to measure how throughput scales with occupancy
-static unsigned dyn_lds_bytes()
-{
-    static const unsigned v = [] { const char *e = std::getenv("AMVS_DYN_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
-    return v;
-}
-
 template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
-#define AMVS_LAUNCH_STEP(U8, M) hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, dyn_lds_bytes(), st, a)
+#define AMVS_LAUNCH_STEP(U8, M) hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, 0, st, a)
     if (a.pairs) {
         if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(true, MODE_REFINE);
         else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(true, MODE_PROP);
@@ -1083,28 +955,6 @@ static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 #undef AMVS_LAUNCH_STEP
     return hipGetLastError();
 }
-#ifdef AMVS_EXPERIMENT_SPLIT
-template <int K, int S>
-static hipError_t launch_sample_ks(const StepArgs &a0, hipStream_t st)
-{
-    // timing experiment: scratch outputs, never read
-    static float *V = nullptr, *dc = nullptr;
-    static uint8_t *ok = nullptr;
-    static long long cap = 0;
-    const long long n = (long long)a0.n_jobs * a0.H * a0.W;
-    if (n > cap) {
-        (void)hipMalloc(&V, sizeof(float) * n * S); (void)hipMalloc(&dc, sizeof(float) * n); (void)hipMalloc(&ok, n);
-        cap = n;
-    }
-    StepArgs a = a0;
-    a.TH = K / 2;
-    constexpr int PX = AMVS_EXPERIMENT_SPLIT;
-    const int nblk = a.n_jobs * ((a.W + 255) / 256) * ((a.H + PX - 1) / PX);
-    if (a.pairs) hipLaunchKernelGGL((pm_sample_kernel<S, true, PX>), dim3(nblk), dim3(256), 0, st, a, V, dc, ok);
-    else hipLaunchKernelGGL((pm_sample_kernel<S, false, PX>), dim3(nblk), dim3(256), 0, st, a, V, dc, ok);
-    return hipGetLastError();
-}
-#endif
 
 template <int K, int S>
 static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
@@ -1155,9 +1005,6 @@ int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 {
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
-#ifdef AMVS_EXPERIMENT_SPLIT
-    if (K == 7 && S == 4) (void)launch_sample_ks<7, 4>(a, st);
-#endif
     switch (K) {
     case 3: AMVS_FOR_S(3, launch_step_ks, a, nblk, st)
     case 5: AMVS_FOR_S(5, launch_step_ks, a, nblk, st)

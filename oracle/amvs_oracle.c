@@ -28,6 +28,22 @@
  *     streams" are defined by the counter-hash generator below, which the golden
  *     capture injects into the reference in place of torch.rand/randn.
  *
+ * TWO ARITHMETIC MODES (orc_ctx_set_mode):
+ *   exact (0): the contract above -- what the reference computes, operation for operation
+ *              up to the box-filter summation order.
+ *   fast  (1): the "tolerance mode" of the HIP backend (include/amvs.h AMVS_MODE_FAST), restated
+ *              here so that HIP-fast can be checked BIT FOR BIT against this file while this
+ *              file is checked against the reference's golden vectors within the tolerances
+ *              tests/test_oracle_golden.py states.  Same algorithm, cheaper arithmetic:
+ *                - images are 8-bit codes (gray = code/255 exactly); sums run in code units;
+ *                - projection precomposed per source: [u z, v z, z] = d * (M [x,y,1]) + b with
+ *                  M = K R_s R_ref^T K^-1, b = K (t_s - R_s R_ref^T t_ref) formed in double;
+ *                - one reciprocal of z, no Markstein quotient refinement, no
+ *                  normalise / un-normalise round trip around grid_sample;
+ *                - bilinear sample as two horizontal lerps and one vertical lerp;
+ *                - reference-image window sums are exact integers.
+ *              Everything else (RNG, candidates, select, NaN/inf conventions) is shared.
+ *
  * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off -fopenmp).
  */
 #include <math.h>
@@ -163,6 +179,7 @@ ORC_API void orc_rng_fill(uint64_t seed, uint32_t view, uint32_t draw, int64_t n
 {
     uint32_t k1, k2;
     stream_keys(seed, view, draw, &k1, &k2);
+#pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         float u, a, b, c;
         rng_draw((uint32_t)i, k1, k2, &u, &a, &b, &c);
@@ -362,6 +379,36 @@ static void ncc_map(const float *img1, const float *mean1, const float *var1,
     }
 }
 
+/* constants of the fast NCC: sums are in code units, statistics in gray units */
+static inline float fast_c1(int k) { return (float)(1.0 / ((double)(k * k) * 255.0)); }
+static inline float fast_c2(int k) { return (float)(1.0 / ((double)(k * k) * 65025.0)); }
+
+/* Fast-mode NCC: img1c / img2 in code units, m1 / v1 the precomputed ref statistics in gray
+ * units; the window sums keep the exact mode's order, the epilogue drops the Markstein
+ * quotient refinement (one multiply by the reciprocal). */
+static void ncc_map_fast(const float *img1c, const float *m1, const float *v1,
+                         const float *img2, int H, int W, int k, int variant,
+                         float *tmp, float *b_v, float *b_vv, float *b_rv, float *out)
+{
+    const float C1 = fast_c1(k), C2 = fast_c2(k);
+    box_sum(img2, NULL, 0, H, W, k, tmp, b_v);
+    box_sum(img2, img2, 1, H, W, k, tmp, b_vv);
+    box_sum(img1c, img2, 1, H, W, k, tmp, b_rv);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < H * W; ++i) {
+        float mean2 = b_v[i] * C1;
+        float var2 = fmaf(-mean2, mean2, b_vv[i] * C2);
+        float cov = fmaf(-m1[i], mean2, b_rv[i] * C2);
+        if (variant == 0) {
+            float den = sqrtf(v1[i] * var2) + 1e-8f;
+            out[i] = 1.0f - cov * (1.0f / den);
+        } else {
+            float den = sqrtf(v1[i] * var2 + 1e-8f);
+            out[i] = cov * (1.0f / den);
+        }
+    }
+}
+
 /* _ncc_cost (mvs_patchmatch.py:392-413) / _compute_ncc_torch (dense_stereo.py:318-347) */
 ORC_API void orc_ncc(const float *img1, const float *img2, int H, int W, int k,
                      int variant, float *out)
@@ -385,6 +432,12 @@ typedef struct {
     float *mean1, *var1;              /* ref stats */
     float *sampled, *tmp, *bv, *bvv, *brv, *cost_s, *total, *count;
     unsigned char *valid;
+    /* fast mode (orc_ctx_set_mode) */
+    int mode;
+    unsigned char *ref_code, *src_code[ORC_MAX_SRC];   /* 8-bit codes of the images */
+    float *ref_codef;                                   /* the same as floats (0..255) */
+    float M[ORC_MAX_SRC][9], bvec[ORC_MAX_SRC][3];      /* precomposed projections */
+    float *m1f, *v1f;                                   /* ref mean / variance (gray units) */
 } orc_ctx_t;
 
 ORC_API orc_ctx_t *orc_ctx_create(int H, int W, int k, const float *K, const float *Kinv,
@@ -415,7 +468,143 @@ ORC_API orc_ctx_t *orc_ctx_create(int H, int W, int k, const float *K, const flo
 ORC_API void orc_ctx_destroy(orc_ctx_t *c)
 {
     if (!c) return;
+    free(c->ref_code); free(c->ref_codef);              /* src codes share ref_code's block */
     free(c->mean1); free(c->valid); free(c);
+}
+
+/* ------------------------------------------------------------ fast mode -- */
+/* M = K R_s R_ref^T K^-1 and b = K (t_s - R_s R_ref^T t_ref), all in double from the float32
+ * operands, rounded to float32 once.  With them  [u z, v z, z]^T = d * M [x,y,1]^T + b  is the
+ * chain back-project -> world -> source camera -> pixel of mvs_patchmatch.py:341-360 in one
+ * affine map per source.  Sums run left to right; K^-1 by cofactors. */
+static void fast_compose(const float *K, const float *Rr, const float *tr,
+                         const float *Rs, const float *ts, float *M, float *b)
+{
+    double Kd[9], Ki[9], Rrel[9], trel[3], A[9];
+    for (int i = 0; i < 9; ++i) Kd[i] = (double)K[i];
+    const double det = Kd[0] * (Kd[4] * Kd[8] - Kd[5] * Kd[7]) - Kd[1] * (Kd[3] * Kd[8] - Kd[5] * Kd[6]) +
+                       Kd[2] * (Kd[3] * Kd[7] - Kd[4] * Kd[6]);
+    Ki[0] = (Kd[4] * Kd[8] - Kd[5] * Kd[7]) / det; Ki[1] = (Kd[2] * Kd[7] - Kd[1] * Kd[8]) / det;
+    Ki[2] = (Kd[1] * Kd[5] - Kd[2] * Kd[4]) / det; Ki[3] = (Kd[5] * Kd[6] - Kd[3] * Kd[8]) / det;
+    Ki[4] = (Kd[0] * Kd[8] - Kd[2] * Kd[6]) / det; Ki[5] = (Kd[2] * Kd[3] - Kd[0] * Kd[5]) / det;
+    Ki[6] = (Kd[3] * Kd[7] - Kd[4] * Kd[6]) / det; Ki[7] = (Kd[1] * Kd[6] - Kd[0] * Kd[7]) / det;
+    Ki[8] = (Kd[0] * Kd[4] - Kd[1] * Kd[3]) / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rrel[3 * i + j] = ((double)Rs[3 * i] * (double)Rr[3 * j] + (double)Rs[3 * i + 1] * (double)Rr[3 * j + 1]) +
+                              (double)Rs[3 * i + 2] * (double)Rr[3 * j + 2];
+    for (int i = 0; i < 3; ++i)
+        trel[i] = (double)ts[i] - ((Rrel[3 * i] * (double)tr[0] + Rrel[3 * i + 1] * (double)tr[1]) +
+                                   Rrel[3 * i + 2] * (double)tr[2]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A[3 * i + j] = (Kd[3 * i] * Rrel[j] + Kd[3 * i + 1] * Rrel[3 + j]) + Kd[3 * i + 2] * Rrel[6 + j];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            M[3 * i + j] = (float)((A[3 * i] * Ki[j] + A[3 * i + 1] * Ki[3 + j]) + A[3 * i + 2] * Ki[6 + j]);
+        b[i] = (float)((Kd[3 * i] * trel[0] + Kd[3 * i + 1] * trel[1]) + Kd[3 * i + 2] * trel[2]);
+    }
+}
+
+/* Select the arithmetic mode of every later call on this context.  Fast mode needs 8-bit images
+ * (every pixel exactly code/255): returns 0 on success, -1 if an image is not 8-bit exact. */
+ORC_API int orc_ctx_set_mode(orc_ctx_t *c, int mode)
+{
+    if (!mode) { c->mode = 0; return 0; }
+    const int H = c->cam.H, W = c->cam.W, k = c->k, h = k / 2;
+    const size_t n = (size_t)H * W;
+    if (!c->ref_code) {
+        unsigned char *codes = (unsigned char *)malloc(n * (size_t)(c->S + 1));
+        for (int v = 0; v <= c->S; ++v) {
+            const float *img = v == 0 ? c->ref : c->src[v - 1];
+            unsigned char *dst = codes + (size_t)v * n;
+            for (size_t i = 0; i < n; ++i) {
+                float q = rintf(img[i] * 255.0f);
+                q = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);
+                dst[i] = (unsigned char)q;
+                if ((float)dst[i] / 255.0f != img[i]) { free(codes); return -1; }
+            }
+        }
+        c->ref_code = codes;
+        for (int s = 0; s < c->S; ++s) c->src_code[s] = codes + (size_t)(s + 1) * n;
+        c->ref_codef = (float *)malloc(sizeof(float) * n * 3);
+        c->m1f = c->ref_codef + n; c->v1f = c->ref_codef + 2 * n;
+        for (size_t i = 0; i < n; ++i) c->ref_codef[i] = (float)codes[i];
+        /* ref window sums: exact integers (<= k*k*255^2 < 2^24), any order */
+        const float C1 = fast_c1(k), C2 = fast_c2(k);
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int sr = 0, srr = 0;
+                for (int i = -h; i <= h; ++i)
+                    for (int j = -h; j <= h; ++j) {
+                        int yy = y + i, xx = x + j;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            int r = codes[(size_t)yy * W + xx];
+                            sr += r; srr += r * r;
+                        }
+                    }
+                float m1 = (float)sr * C1;
+                c->m1f[(size_t)y * W + x] = m1;
+                c->v1f[(size_t)y * W + x] = fmaf(-m1, m1, (float)srr * C2);
+            }
+        for (int s = 0; s < c->S; ++s)
+            fast_compose(c->cam.K, c->cam.Rref, c->cam.tref, c->Rs[s], c->ts[s], c->M[s], c->bvec[s]);
+    }
+    c->mode = 1;
+    return 0;
+}
+
+static inline uint32_t f32_bits(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+
+/* Fast-mode projection + bilinear sample of source s at pixel (x,y), depth d; the result is in
+ * code units (0..255).  bounds as in project_sample.  Validity: z > 0.1 and, with u' = u - lo,
+ * 0 <= u' < W - 2 lo tested as ONE unsigned compare of the float's bit pattern (a negative or
+ * NaN u' has a bit pattern above every non-negative bound); the same for v'. */
+static inline float project_sample_fast(const orc_ctx_t *c, int s, int x, int y, float d,
+                                        int half, int bounds, int *valid)
+{
+    const int H = c->cam.H, W = c->cam.W;
+    const float *M = c->M[s], *b = c->bvec[s];
+    const unsigned char *img = c->src_code[s];
+    const float fx = (float)x, fy = (float)y;
+    float q0 = fmaf(M[1], fy, fmaf(M[0], fx, M[2]));
+    float q1 = fmaf(M[4], fy, fmaf(M[3], fx, M[5]));
+    float q2 = fmaf(M[7], fy, fmaf(M[6], fx, M[8]));
+    float p0 = fmaf(d, q0, b[0]), p1 = fmaf(d, q1, b[1]), p2 = fmaf(d, q2, b[2]);
+    float zz = p2 + 1e-8f;
+    float rz = 1.0f / zz;
+    const int lo = bounds == 0 ? half : 0;
+    float up = fmaf(p0, rz, -(float)lo), vp = fmaf(p1, rz, -(float)lo);
+    int ok = p2 > 0.1f;
+    if (bounds != 2)
+        ok = ok && f32_bits(up) < f32_bits((float)(W - 2 * lo)) && f32_bits(vp) < f32_bits((float)(H - 2 * lo));
+    *valid = ok;
+    float x0 = floorf(up), y0 = floorf(vp);
+    float wx = up - x0, wy = vp - y0;
+    /* footprint origin clamped to true image coordinates [-2, W] x [-2, H]; NaN -> lower bound */
+    const float xlo = -(float)(2 + lo), xhi = (float)(W - lo), yhi = (float)(H - lo);
+    float xc = !(x0 >= xlo) ? xlo : (x0 > xhi ? xhi : x0);
+    float yc = !(y0 >= xlo) ? xlo : (y0 > yhi ? yhi : y0);
+    const int xi = (int)xc + lo, yi = (int)yc + lo;
+    float t[4];
+    for (int k = 0; k < 4; ++k) {
+        int xx = xi + (k & 1), yy = yi + (k >> 1);
+        t[k] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? (float)img[(size_t)yy * W + xx] : 0.0f;
+    }
+    float top = fmaf(wx, t[1] - t[0], t[0]);
+    float bot = fmaf(wx, t[3] - t[2], t[2]);
+    return fmaf(wy, bot - top, top);
+}
+
+/* NCC of the context's reference image against a sampled image, in the context's mode */
+static void ctx_ncc(orc_ctx_t *c, const float *sampled, int variant, float *out)
+{
+    const int H = c->cam.H, W = c->cam.W;
+    if (c->mode)
+        ncc_map_fast(c->ref_codef, c->m1f, c->v1f, sampled, H, W, c->k, variant, c->tmp, c->bv, c->bvv, c->brv, out);
+    else
+        ncc_map(c->ref, c->mean1, c->var1, sampled, H, W, c->k, variant, c->tmp, c->bv, c->bvv, c->brv, out);
 }
 
 /* sample source s at per-pixel depth map `depth` -> sampled image + validity */
@@ -423,6 +612,16 @@ static void sample_source(orc_ctx_t *c, int s, const float *depth, int bounds,
                           float *sampled, unsigned char *valid)
 {
     const int H = c->cam.H, W = c->cam.W, half = c->k / 2;
+    if (c->mode) {
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                int ok;
+                sampled[y * W + x] = project_sample_fast(c, s, x, y, depth[y * W + x], half, bounds, &ok);
+                valid[y * W + x] = (unsigned char)ok;
+            }
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
@@ -447,17 +646,21 @@ ORC_API void orc_patch_cost(orc_ctx_t *c, const float *depth, float *cost_out)
 {
     const int H = c->cam.H, W = c->cam.W;
     const size_t n = (size_t)H * W;
+    (void)H; (void)W;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) { c->total[i] = 0.0f; c->count[i] = 0.0f; }
     for (int s = 0; s < c->S; ++s) {
         sample_source(c, s, depth, 0, c->sampled, c->valid);
-        ncc_map(c->ref, c->mean1, c->var1, c->sampled, H, W, c->k, 0,
-                c->tmp, c->bv, c->bvv, c->brv, c->cost_s);
+        ctx_ncc(c, c->sampled, 0, c->cost_s);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i)
             if (c->valid[i]) { c->total[i] = c->total[i] + c->cost_s[i]; c->count[i] += 1.0f; }
     }
+    const int fast = c->mode;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float cden = c->count[i] + 1e-8f;
-        float avg = qdiv(c->total[i], cden, 1.0f / cden);
+        float avg = fast ? c->total[i] * (1.0f / cden) : qdiv(c->total[i], cden, 1.0f / cden);
         cost_out[i] = (c->count[i] >= 2.0f) ? avg : INFINITY;
     }
 }
@@ -467,11 +670,12 @@ ORC_API void orc_confidence(orc_ctx_t *c, const float *depth, float *conf_out)
 {
     const int H = c->cam.H, W = c->cam.W;
     const size_t n = (size_t)H * W;
+    (void)H; (void)W;
     for (size_t i = 0; i < n; ++i) conf_out[i] = 0.0f;
     for (int s = 0; s < c->S; ++s) {
         sample_source(c, s, depth, 1, c->sampled, c->valid);
-        ncc_map(c->ref, c->mean1, c->var1, c->sampled, H, W, c->k, 0,
-                c->tmp, c->bv, c->bvv, c->brv, c->cost_s);
+        ctx_ncc(c, c->sampled, 0, c->cost_s);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i) {
             float ncc = 1.0f - c->cost_s[i];          /* :530 */
             if (c->valid[i] && ncc > 0.6f) conf_out[i] += 1.0f;
@@ -489,6 +693,7 @@ ORC_API void orc_propagate_step(orc_ctx_t *c, float *depth, float *normal, float
     const size_t n = (size_t)H * W;
     float *cd = (float *)calloc(n * 5, sizeof(float));
     float *cn = cd + n, *cc = cd + 4 * n;
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             int yy = y + oy, xx = x + ox;
@@ -503,6 +708,7 @@ ORC_API void orc_propagate_step(orc_ctx_t *c, float *depth, float *normal, float
             }
         }
     orc_patch_cost(c, cd, cc);
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i)
         if (cc[i] < cost[i]) {                                   /* :452-455 */
             depth[i] = cd[i]; cost[i] = cc[i];
@@ -536,6 +742,7 @@ ORC_API void orc_refine_step(orc_ctx_t *c, float *depth, float *normal, float *c
     const size_t n = (size_t)c->cam.H * c->cam.W;
     float *cd = (float *)calloc(n * 5, sizeof(float));
     float *cn = cd + n, *cc = cd + 4 * n;
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i) {
         float delta = (u[i] * 2.0f - 1.0f) * depth_range;        /* :471 */
         float d = depth[i] + delta;                              /* :472 */
@@ -549,6 +756,7 @@ ORC_API void orc_refine_step(orc_ctx_t *c, float *depth, float *normal, float *c
         cn[3 * i] = a; cn[3 * i + 1] = b; cn[3 * i + 2] = e;
     }
     orc_patch_cost(c, cd, cc);
+#pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; ++i)
         if (cc[i] < cost[i]) {                                   /* :486-489 */
             depth[i] = cd[i]; cost[i] = cc[i];
@@ -614,14 +822,16 @@ ORC_API void orc_plane_sweep(orc_ctx_t *c, const float *depths, int D, float thr
     float *votes = dmap + n;
     for (size_t i = 0; i < n; ++i) { conf_out[i] = -1.0f; depth_out[i] = 0.0f; }
     for (int d = 0; d < D; ++d) {
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i) { dmap[i] = depths[d]; votes[i] = 0.0f; }
         for (int s = 0; s < c->S; ++s) {
             sample_source(c, s, dmap, 2, c->sampled, c->valid);
-            ncc_map(c->ref, c->mean1, c->var1, c->sampled, H, W, c->k, 1,
-                    c->tmp, c->bv, c->bvv, c->brv, c->cost_s);
+            ctx_ncc(c, c->sampled, 1, c->cost_s);
+#pragma omp parallel for schedule(static)
             for (size_t i = 0; i < n; ++i)
                 if (c->cost_s[i] > thresh && c->valid[i]) votes[i] += 1.0f;       /* :303-304 */
         }
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < n; ++i)
             if (votes[i] > conf_out[i]) { conf_out[i] = votes[i]; depth_out[i] = depths[d]; }
     }

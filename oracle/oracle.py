@@ -39,6 +39,8 @@ def lib():
                                      C.c_int, f32p, f32p, f32p]
         L.orc_ctx_create.restype = C.c_void_p
         L.orc_ctx_destroy.argtypes = [C.c_void_p]
+        L.orc_ctx_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ctx_set_mode.restype = C.c_int
         L.orc_sample.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int, f32p, u8p]
         L.orc_patch_cost.argtypes = [C.c_void_p, f32p, f32p]
         L.orc_confidence.argtypes = [C.c_void_p, f32p, f32p]
@@ -99,7 +101,7 @@ class ViewContext:
     """One reference view + its source views (the arguments of
     PatchMatchMVS._compute_patch_cost, mvs_patchmatch.py:323-329)."""
 
-    def __init__(self, K, ref, R_ref, t_ref, srcs, Rs, ts, patch, K_inv=None):
+    def __init__(self, K, ref, R_ref, t_ref, srcs, Rs, ts, patch, K_inv=None, mode="exact"):
         self.K, kp = _f(np.asarray(K, np.float32).reshape(3, 3))
         if K_inv is None:
             K_inv = np.linalg.inv(self.K)
@@ -117,6 +119,18 @@ class ViewContext:
                                        self.S, sp, rsp, tsp)
         if not self._h:
             raise RuntimeError("orc_ctx_create failed")
+        self.mode = "exact"
+        if mode != "exact":
+            self.set_mode(mode)
+
+    def set_mode(self, mode):
+        """'exact' (the reference's arithmetic) or 'fast' (the HIP backend's tolerance mode,
+        8-bit images only); applies to every later call."""
+        if mode not in ("exact", "fast"):
+            raise ValueError(mode)
+        if lib().orc_ctx_set_mode(self._h, 1 if mode == "fast" else 0) != 0:
+            raise ValueError("fast mode needs 8-bit images (every pixel exactly code/255)")
+        self.mode = mode
 
     def close(self):
         if self._h:

@@ -12,7 +12,7 @@ mathematically identical re-ordering of its box filter).
 """
 import numpy as np
 
-from conftest import assert_cost_close, load_golden
+from conftest import CONF_HIST_TOL, E2E_MIN_FRACTION, assert_cost_close, load_golden
 from oracle import oracle
 
 COST_ATOL = 1e-4
@@ -134,8 +134,9 @@ def test_g05_refine(scene_a):
 
 
 def test_g06_patchmatch_end_to_end(scene_b):
-    """_patchmatch_cuda on identical RNG streams: depth within 1e-3 relative on >= 97 % of
-    pixels (north-star tolerance as a pixel fraction), confidence histogram within 2 %."""
+    """_patchmatch_cuda on identical RNG streams: depth within 1e-3 relative on >= 98 % of
+    pixels (north-star tolerance as a pixel fraction; measured 100 %), confidence histogram
+    within 1 % (measured identical)."""
     g = load_golden("g06_patchmatch_e2e")
     for r in g["refs"]:
         r = int(r)
@@ -145,12 +146,12 @@ def test_g06_patchmatch_end_to_end(scene_b):
         wd, wn, wc = g[f"depth_{r}"], g[f"normal_{r}"], g[f"confidence_{r}"]
         rel = np.abs(d - wd) / wd
         frac = np.mean(rel <= 1e-3)
-        assert frac >= 0.97, f"view {r}: {frac:.4f} of pixels within 1e-3 relative"
+        assert frac >= E2E_MIN_FRACTION, f"view {r}: {frac:.4f} of pixels within 1e-3 relative"
         same = rel <= 1e-6
         assert np.abs(n[same] - wn[same]).max() < 1e-4
         hist_got = np.bincount(conf.astype(int).ravel(), minlength=5) / conf.size
         hist_want = np.bincount(wc.astype(int).ravel(), minlength=5) / wc.size
-        assert np.abs(hist_got - hist_want).max() < 0.02
+        assert np.abs(hist_got - hist_want).max() < CONF_HIST_TOL
 
 
 def test_g06_first_steps_bit_identical_hypotheses(scene_b):
