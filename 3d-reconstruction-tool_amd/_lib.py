@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
+MODES = {"default": 0, "exact": 1, "fast": 2}
 SUPPORTED_PATCH_SIZES = (3, 5, 7, 9, 11)
 
 f32p = C.POINTER(C.c_float)
@@ -21,7 +22,7 @@ class PmParams(C.Structure):
     _fields_ = [("patch_size", C.c_int32), ("num_iterations", C.c_int32),
                 ("num_samples", C.c_int32), ("tile_rows", C.c_int32), ("views_per_launch", C.c_int32),
                 ("depth_min", C.c_float), ("depth_max", C.c_float),
-                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float)]
+                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float), ("mode", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -46,6 +47,10 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_get_timing": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "amvs_sampling_mode": (C.c_int, [C.c_void_p]),
+    "amvs_set_sampling": (C.c_int, [C.c_void_p, C.c_int]),
+    "amvs_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "amvs_get_mode": (C.c_int, [C.c_void_p]),
+    "amvs_set_sweep_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "amvs_last_tile_rows": (C.c_int, [C.c_void_p]),
     "amvs_last_views_per_launch": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,
@@ -53,6 +58,8 @@ SIGNATURES = {
     "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,
                                           C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "amvs_eval_cost": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_sample_sources": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f32p, f32p,
+                                      C.POINTER(C.c_uint8)]),
     "amvs_confidence": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
     "amvs_propagate_step": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p, f32p,
                                       C.c_int, C.c_int, C.c_float]),

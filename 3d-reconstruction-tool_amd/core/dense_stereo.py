@@ -25,7 +25,7 @@ class DenseStereoReconstructor:
 
     def __init__(self, camera: Camera, scale: float = 0.25, num_depths: int = 64,
                  patch_size: int = 5, min_views: int = 3, consistency_thresh: float = 0.8, *,
-                 device: Optional[int] = None, device_filter: bool = True):
+                 device: Optional[int] = None, device_filter: bool = True, mode: str = "fast"):
         self.camera = camera
         self.scale = scale
         self.num_depths = num_depths
@@ -34,6 +34,9 @@ class DenseStereoReconstructor:
         self.consistency_thresh = consistency_thresh
         self.device_id = _parallel.local_device() if device is None else int(device)
         self.device_filter = device_filter       # outlier filter's neighbour search on the GPU
+        if mode not in ("exact", "fast"):
+            raise ValueError("mode must be 'exact' or 'fast'")
+        self.mode = mode                         # arithmetic of the sweep (include/amvs.h AMVS_MODE_*)
         print(f"Dense stereo using GPU: HIP device {self.device_id} (gfx950 kernels)")
         # fx, fy, cx, cy scaled (reference :55-59)
         self.K_scaled = camera.K.copy()
@@ -41,6 +44,7 @@ class DenseStereoReconstructor:
             self.K_scaled[r, c] *= scale
         self._engine = None
         self._engine_key = None
+        self._engine_images = None
         self._slot = {}
 
     def reconstruct(self, images: List[dict], poses: Dict[int, CameraPose],
@@ -111,17 +115,22 @@ class DenseStereoReconstructor:
 
     def _ensure_engine(self, processed: Dict, poses: Dict[int, CameraPose]):
         indices = sorted(processed.keys())
-        key = (id(processed), tuple(indices))
-        if self._engine is not None and self._engine_key == key:
+        H, W = processed[indices[0]]["shape"]
+        # strong reference to the dict + pose fingerprint (see PatchMatchMVS._ensure_engine)
+        pose_print = b"".join(np.asarray(poses[i].R, np.float64).tobytes() + np.asarray(poses[i].t, np.float64).tobytes()
+                              for i in indices)
+        key = (tuple(indices), (int(H), int(W)), pose_print, self.K_scaled.tobytes(), self.device_id)
+        if self._engine is not None and self._engine_images is processed and self._engine_key == key:
             return self._engine
         if self._engine is not None:
             self._engine.close()
-        H, W = processed[indices[0]]["shape"]
-        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id)
+            self._engine = None
+        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id,
+                             mode=self.mode)
         self._slot = {idx: s for s, idx in enumerate(indices)}
         for idx in indices:
             eng.set_view(self._slot[idx], processed[idx]["gray"], poses[idx].R, poses[idx].t)
-        self._engine, self._engine_key = eng, key
+        self._engine, self._engine_key, self._engine_images = eng, key, processed
         return eng
 
     def _compute_depth_map_gpu(self, ref_idx: int, neighbor_indices: List[int], processed: Dict,

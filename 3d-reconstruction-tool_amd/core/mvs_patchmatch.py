@@ -13,6 +13,11 @@ Differences a caller can observe, all opt-in or performance-only:
   * every view is uploaded once and all reference views are swept in batches
     (the reference re-uploads per view and loops serially, :104-123, :235-257);
   * `seed` names the RNG streams (the reference is unseeded);
+  * `mode` selects the arithmetic of the sweep kernels: "exact" reproduces the reference's float32
+    operation sequence (bit-identical to the tests' CPU restatement, which matches torch-CPU up to
+    the box filter's summation order), "fast" (default) is the tolerance mode of include/amvs.h
+    AMVS_MODE_FAST -- measured against the reference's golden vectors it agrees exactly as well
+    as "exact" does (see DESIGN.md section 2);
   * under an initialised torch.distributed process group the reference views are
     sharded over ranks and the per-view maps are all-gathered (see ..parallel);
   * with `device_fusion` (default) and torch-ROCm present the per-view maps never leave
@@ -71,7 +76,7 @@ class PatchMatchMVS:
                  num_iterations: int = 3, num_samples: int = 8, min_views: int = 3,
                  depth_min: float = 0.1, depth_max: float = 100.0, *,
                  seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
-                 process_group=None, device_fusion: bool = True):
+                 process_group=None, device_fusion: bool = True, mode: str = "fast"):
         self.camera = camera
         self.scale = scale
         self.patch_size = patch_size
@@ -84,6 +89,9 @@ class PatchMatchMVS:
         self.views_per_batch = max(1, int(views_per_batch))
         self.process_group = process_group
         self.device_fusion = device_fusion
+        if mode not in ("exact", "fast"):
+            raise ValueError("mode must be 'exact' or 'fast'")
+        self.mode = mode
         self.device_id = _parallel.local_device() if device is None else int(device)
         print(f"PatchMatch MVS using GPU: HIP device {self.device_id} (gfx950 kernels)")
         # scaled intrinsics: first two rows times `scale` (reference :69-70)
@@ -91,6 +99,7 @@ class PatchMatchMVS:
         self.K_scaled[:2] *= scale
         self._engine = None
         self._engine_key = None
+        self._engine_images = None       # strong reference to the prepared dict the engine holds
         self._slot = {}
         self.last_timing = None
 
@@ -198,16 +207,22 @@ class PatchMatchMVS:
     # ----------------------------------------------------------------- device -----
     def _pm_params(self):
         return _engine.make_pm_params(self.patch_size, self.num_iterations, self.num_samples,
-                                      self.depth_min, self.depth_max)
+                                      self.depth_min, self.depth_max, mode=self.mode)
 
     def _ensure_engine(self, images: Dict, poses: Dict[int, CameraPose], indices: List[int]):
-        """Upload every view once; cached while the same prepared-image dict is in use."""
-        key = (id(images), tuple(indices))
-        if self._engine is not None and self._engine_key == key:
+        """Upload every view once; cached while the same prepared-image dict, the same poses and
+        the same intrinsics are in use.  The key holds a strong reference to the dict (an id() of a
+        freed dict can be reused by CPython) and a fingerprint of every R|t, so a second call with
+        refined poses re-uploads instead of sweeping with stale ones."""
+        H, W = images[indices[0]]["shape"]
+        pose_print = b"".join(np.asarray(poses[i].R, np.float64).tobytes() + np.asarray(poses[i].t, np.float64).tobytes()
+                              for i in indices)
+        key = (tuple(indices), (int(H), int(W)), pose_print, self.K_scaled.tobytes(), self.device_id)
+        if self._engine is not None and self._engine_images is images and self._engine_key == key:
             return self._engine
         if self._engine is not None:
             self._engine.close()
-        H, W = images[indices[0]]["shape"]
+            self._engine = None
         for idx in indices:
             if tuple(images[idx]["shape"]) != (H, W):
                 raise ValueError("all views must share one processed size")
@@ -215,7 +230,7 @@ class PatchMatchMVS:
         self._slot = {idx: s for s, idx in enumerate(indices)}
         for idx in indices:
             eng.set_view(self._slot[idx], images[idx]["gray"], poses[idx].R, poses[idx].t)
-        self._engine, self._engine_key = eng, key
+        self._engine, self._engine_key, self._engine_images = eng, key, images
         return eng
 
     def _run_batch(self, eng, batch):
@@ -261,7 +276,7 @@ class PatchMatchMVS:
                           f"{valid:,} valid pixels ({per_view:.1f}s)")
         if world > 1:
             local = _parallel.allgather_maps(local, len(jobs), proc_images[cam_indices[0]]["shape"],
-                                             self.process_group, DepthNormalMap)
+                                             self.process_group, DepthNormalMap, device_id=self.device_id)
         return {jobs[j][0]: local[j] for j in sorted(local)}
 
     def _sweep_resident(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":

@@ -10,7 +10,6 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -24,6 +23,11 @@ std::string g_create_error;
 
 struct Stats {
     float *mean = nullptr, *var = nullptr;
+    std::vector<char> done;
+};
+
+struct FastStats {
+    float2 *maps = nullptr;             // [n_views][H*W]
     std::vector<char> done;
 };
 
@@ -43,8 +47,11 @@ struct amvs_ctx {
     long long pstride = 0;              // ushorts between packed maps
     int *d_flag = nullptr;
     std::vector<char> exact8;
-    bool force_f32 = false;             // AMVS_FORCE_F32_SAMPLING=1: A/B switch for tests
+    bool force_f32 = false;             // amvs_set_sampling: A/B switch for tests
+    int mode = AMVS_MODE_EXACT;         // arithmetic of the sweeps (amvs_set_mode)
+    int sweep_tile_rows = 0, sweep_chunk = 0;   // amvs_set_sweep_tuning (0 = automatic)
     std::map<int, Stats> stats;
+    std::map<int, FastStats> fstats;    // fast mode: (mean1, var1) maps per patch size
     int cap_slots = 0;
     float *d_depth[2] = {nullptr, nullptr}, *d_cost[2] = {nullptr, nullptr},
           *d_normal[2] = {nullptr, nullptr}, *d_aux = nullptr;
@@ -151,9 +158,36 @@ int ensure_stats(amvs_ctx *c, int patch)
     return AMVS_OK;
 }
 
-int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src)
+// fast mode: (mean1, var1) of every uploaded view for this patch size (exact integer window sums
+// of the 8-bit codes), computed once and kept resident
+int ensure_fast_stats(amvs_ctx *c, int patch)
+{
+    FastStats &s = c->fstats[patch];
+    const size_t hw = (size_t)c->H * c->W;
+    if (!s.maps) {
+        HIPCHK(c, hipMalloc(&s.maps, sizeof(float2) * hw * c->n_views));
+        s.done.assign(c->n_views, 0);
+    }
+    for (int v = 0; v < c->n_views; ++v) {
+        if (!c->have[v] || s.done[v]) continue;
+        HIPCHK(c, amvs::launch_fast_stats(patch, c->d_pairs + (long long)v * c->pstride, c->H, c->W,
+                                          s.maps + (size_t)v * hw, c->stream));
+        s.done[v] = 1;
+    }
+    return AMVS_OK;
+}
+
+// `fast_patch` > 0: also fill the fast-mode records (precomposed projections, ref statistics of
+// that patch size)
+int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, int fast_patch = 0)
 {
     if (n_ref <= 0 || !ref_ids || !src_ids) return fail(c, AMVS_EINVAL, "empty batch");
+    const float2 *fmaps = nullptr;
+    if (fast_patch > 0) {
+        int rc = ensure_fast_stats(c, fast_patch);
+        if (rc) return rc;
+        fmaps = c->fstats[fast_patch].maps;
+    }
     std::vector<amvs::Job> jobs(n_ref);
     for (int i = 0; i < n_ref; ++i) {
         amvs::Job &j = jobs[i];
@@ -168,6 +202,7 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
         j.ref_img = r;
         j.ref_pairs = (unsigned long long)(uintptr_t)(c->d_pairs + (long long)r * c->pstride) +
                       (unsigned long long)(amvs::pair_map_origin(c->W) * amvs::pair_map_texel_bytes());
+        j.ref_stats = fmaps ? (unsigned long long)(uintptr_t)(fmaps + (size_t)r * c->H * c->W) : 0ull;
         j.stream_view = (uint32_t)r;
         j.slot = i;
         j.n_src = n_src;
@@ -179,6 +214,11 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             j.src[s].gray = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
             std::memcpy(j.src[s].R, c->R[v].data(), 36);
             std::memcpy(j.src[s].t, c->t[v].data(), 12);
+            if (fast_patch > 0) {
+                amvs::fast_compose(c->K, c->R[r].data(), c->t[r].data(), c->R[v].data(), c->t[v].data(),
+                                   j.fsrc[s].M, j.fsrc[s].b);
+                j.fsrc[s].pairs = j.src[s].pairs;
+            }
         }
     }
     int rc = ensure_jobs(c, n_ref);
@@ -198,6 +238,19 @@ const uint16_t *usable_pairs(const amvs_ctx *c)
     return c->d_pairs;
 }
 
+// 1 when the sweeps of this call run in the fast arithmetic; fails when fast was asked for but
+// some uploaded view is not 8-bit exact (the fast kernels sample the packed maps only)
+int resolve_fast(amvs_ctx *c, int requested, int *fast)
+{
+    const int m = requested == AMVS_MODE_DEFAULT ? c->mode : requested;
+    if (m != AMVS_MODE_EXACT && m != AMVS_MODE_FAST) return fail(c, AMVS_EINVAL, "unknown arithmetic mode");
+    *fast = m == AMVS_MODE_FAST;
+    if (*fast && !usable_pairs(c))
+        return fail(c, AMVS_EUNSUPPORTED,
+                    "fast mode needs 8-bit images (every uploaded view exactly code/255) and packed sampling");
+    return AMVS_OK;
+}
+
 // Views swept together by one launch.  Measured on MI355X (16 views 1080p, k=7, S=4, G px-hyp/s):
 // 1 view 20.0, 2: 26.3, 4: 28.5, 8: 30.9, 16: 31.8 -- filling the chip matters more than keeping a
 // small group's state resident in the Infinity Cache, so the default is the whole batch (capped so
@@ -212,11 +265,12 @@ int default_views_per_launch(const amvs_ctx *c, int n_ref)
 // the launch needs several strips per resident wave slot to keep all CUs busy to the end.
 // Measured on MI355X (16 views 1080p, k=7): 16 rows 24.6, 32 rows 25.3-26.7, 64 rows 24.1-24.7,
 // 128 rows 20.0 G px-hyp/s -- so 32 rows when that yields >= 3 strips per slot, else shorter.
-int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap)
+int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap, bool fast = false)
 {
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
-    const long long slots = (long long)c->n_cu * amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr);
+    const long long slots = (long long)c->n_cu * (fast ? amvs::step_fast_waves_per_cu(patch, n_src)
+                                                       : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr));
     // measured on MI355X (S=4, 16 views 1080p; best strip height per patch size): k=3: 10-12 rows,
     // k=5: 14-18, k=7: 20-26 (32: -3 %, 40+: -15 %), k=9: 24-32, k=11: 32-40, i.e. about 4k-4: smaller
     // patches leave more waves resident, and what matters is the set of source rows the resident
@@ -303,9 +357,12 @@ int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     if (rc) return rc;
     if ((rc = check_patch_src(c, patch, n_src))) return rc;
     if ((rc = ensure_slots(c, 1))) return rc;
-    if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src))) return rc;
+    int fast = 0;
+    if ((rc = resolve_fast(c, AMVS_MODE_DEFAULT, &fast))) return rc;
+    if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src, fast ? patch : 0))) return rc;
     o.c = c; o.patch = patch; o.n_src = n_src; o.hw = (size_t)c->H * c->W;
-    o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64));
+    o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64, fast != 0));
+    o.a.fast = fast;
     o.a.mode = amvs::MODE_EVAL;
     set_io(o.a, c, 0, 0);
     return AMVS_OK;
@@ -359,10 +416,6 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     c->R.resize(n_views); c->t.resize(n_views); c->have.assign(n_views, 0);
     c->exact8.assign(n_views, 0);
     c->pstride = ((amvs::pair_map_elems(H, W) + 63) / 64) * 64 + 64;
-    {
-        const char *e = std::getenv("AMVS_FORCE_F32_SAMPLING");
-        c->force_f32 = e && e[0] == '1';
-    }
     auto bail = [&](const char *what, hipError_t e) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         amvs_destroy(c);
@@ -416,6 +469,8 @@ int amvs_destroy(amvs_ctx *c)
         if (kv.second.mean) (void)hipFree(kv.second.mean);
         if (kv.second.var) (void)hipFree(kv.second.var);
     }
+    for (auto &kv : c->fstats)
+        if (kv.second.maps) (void)hipFree(kv.second.maps);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_groups) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -461,6 +516,7 @@ static int set_view_common(amvs_ctx *c, int view, const void *gray, const float 
     std::memcpy(c->t[view].data(), t, 12);
     c->have[view] = 1;
     for (auto &kv : c->stats) if (!kv.second.done.empty()) kv.second.done[view] = 0;
+    for (auto &kv : c->fstats) if (!kv.second.done.empty()) kv.second.done[view] = 0;
     return AMVS_OK;
 }
 
@@ -485,18 +541,16 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if (rc) return rc;
     if ((rc = check_patch_src(c, p->patch_size, n_src))) return rc;
     if ((rc = ensure_slots(c, n_ref))) return rc;
-    if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src))) return rc;
+    int fast = 0;
+    if ((rc = resolve_fast(c, p->mode, &fast))) return rc;
+    if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src, fast ? p->patch_size : 0))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
     // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
     // `vpl` views, each group through the whole schedule (see default_views_per_launch).
     int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
-    if (const char *e = std::getenv("AMVS_VIEWS_PER_LAUNCH")) {
-        const int v = std::atoi(e);
-        if (v >= 1) vpl = v;
-    }
     if (vpl > n_ref) vpl = n_ref;
-    const int TH = pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20);
+    const int TH = pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0);
     c->last_tile_rows = TH;
     resolve_timing(c);
     c->timing = amvs_timing{};
@@ -515,6 +569,7 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     for (int g = 0; g < n_groups; ++g) {
         const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
         amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
+        a.fast = fast;
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;
@@ -608,6 +663,32 @@ int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
 
 int amvs_sampling_mode(const amvs_ctx *c) { return c && usable_pairs(c) ? 1 : 0; }
 
+int amvs_set_mode(amvs_ctx *c, int mode)
+{
+    if (!c) return AMVS_EINVAL;
+    if (mode != AMVS_MODE_EXACT && mode != AMVS_MODE_FAST) return fail(c, AMVS_EINVAL, "unknown arithmetic mode");
+    c->mode = mode;
+    return AMVS_OK;
+}
+
+int amvs_get_mode(const amvs_ctx *c) { return c ? c->mode : AMVS_EINVAL; }
+
+int amvs_set_sampling(amvs_ctx *c, int force_f32)
+{
+    if (!c) return AMVS_EINVAL;
+    c->force_f32 = force_f32 != 0;
+    return AMVS_OK;
+}
+
+int amvs_set_sweep_tuning(amvs_ctx *c, int tile_rows, int chunk)
+{
+    if (!c) return AMVS_EINVAL;
+    if (tile_rows < 0 || tile_rows > AMVS_SWEEP_MAX_TH || chunk < 0)
+        return fail(c, AMVS_EINVAL, "plane-sweep tuning out of range");
+    c->sweep_tile_rows = tile_rows; c->sweep_chunk = chunk;
+    return AMVS_OK;
+}
+
 int amvs_last_tile_rows(const amvs_ctx *c) { return c ? c->last_tile_rows : 0; }
 
 int amvs_last_views_per_launch(const amvs_ctx *c) { return c ? c->last_views_per_launch : 0; }
@@ -621,7 +702,9 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     int rc = bind_device(c);
     if (rc) return rc;
     if ((rc = check_patch_src(c, patch_size, n_nbr))) return rc;
-    if ((rc = upload_jobs(c, n_ref, ref_ids, nbr_ids, n_nbr))) return rc;
+    int fast = 0;
+    if ((rc = resolve_fast(c, AMVS_MODE_DEFAULT, &fast))) return rc;
+    if ((rc = upload_jobs(c, n_ref, ref_ids, nbr_ids, n_nbr, fast ? patch_size : 0))) return rc;
     if (D > c->cap_planes) {
         if (c->d_planes) (void)hipFree(c->d_planes);
         c->d_planes = nullptr; c->cap_planes = 0;
@@ -642,10 +725,8 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     // tall strips (little halo re-sampling); the planes are chunked so that the launch still has
     // about four strips per resident wave slot
     a.TH = AMVS_SWEEP_MAX_TH < c->H ? AMVS_SWEEP_MAX_TH : c->H;
-    if (const char *e = std::getenv("AMVS_SWEEP_TILE_ROWS")) {
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= AMVS_SWEEP_MAX_TH) a.TH = v;
-    }
+    if (c->sweep_tile_rows >= 1 && c->sweep_tile_rows <= AMVS_SWEEP_MAX_TH && c->sweep_tile_rows < a.TH)
+        a.TH = c->sweep_tile_rows;
     a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
     a.tiles_y = (c->H + a.TH - 1) / a.TH;
     a.n_jobs = n_ref; a.D = D;
@@ -656,10 +737,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
         if (want < 1) want = 1;
         if (want > D) want = D;
         a.chunk = (int)((D + want - 1) / want);
-        if (const char *e = std::getenv("AMVS_SWEEP_CHUNK")) {
-            const int v = std::atoi(e);
-            if (v >= 1) a.chunk = v < D ? v : D;
-        }
+        if (c->sweep_chunk >= 1) a.chunk = c->sweep_chunk < D ? c->sweep_chunk : D;
         if (a.chunk > AMVS_SWEEP_MAX_CHUNK) a.chunk = AMVS_SWEEP_MAX_CHUNK;
         a.n_chunks = (D + a.chunk - 1) / a.chunk;
     }
@@ -668,6 +746,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.images = c->d_images;
     a.pairs = usable_pairs(c);
     a.pair_stride = c->pstride;
+    a.fast = fast;
     a.depths = c->d_planes;
     a.thresh = thresh;
     a.depth_out = (float *)depth_dev; a.conf_out = (float *)conf_dev;
@@ -720,6 +799,30 @@ int amvs_eval_cost(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
     HIPCHK(c, hipMemcpyAsync(cost_out, c->d_aux, 4 * o.hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AMVS_OK;
+}
+
+int amvs_sample_sources(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size, int bounds,
+                        const float *depth_in, float *sampled_out, uint8_t *valid_out)
+{
+    OneStep o;
+    int rc = one_step_begin(c, ref, src_ids, n_src, patch_size, o);
+    if (rc) return rc;
+    if (!depth_in || !sampled_out || !valid_out || bounds < 0 || bounds > 2) return fail(c, AMVS_EINVAL, "bad argument");
+    if ((rc = upload_state(c, o.hw, depth_in, nullptr, nullptr))) return rc;
+    float *ds = nullptr;
+    unsigned char *dv = nullptr;
+    HIPCHK(c, hipMalloc(&ds, 4 * o.hw * n_src));
+    hipError_t e = hipMalloc(&dv, o.hw);
+    o.a.TH = patch_size / 2;
+    o.a.mode = bounds == 0 ? amvs::MODE_EVAL : (bounds == 1 ? amvs::MODE_CONF : amvs::MODE_EVAL + 100);
+    if (e == hipSuccess) e = amvs::launch_sample_dump(n_src, o.a, ds, dv, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sampled_out, ds, 4 * o.hw * n_src, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(valid_out, dv, o.hw, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(ds);
+    if (dv) (void)hipFree(dv);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("sample_sources: ") + hipGetErrorString(e));
     return AMVS_OK;
 }
 

@@ -1,0 +1,75 @@
+// amvs_kernel_common.h -- device helpers shared by the exact (amvs_kernels.hip) and the fast
+// (amvs_kernels_fast.hip) sweep kernels.
+#pragma once
+#include "amvs_kernels.h"
+#include "amvs_device.h"
+
+#include <type_traits>
+
+namespace amvs {
+
+// The job table is never written while a sweep kernel runs: reading it through the
+// constant address space lets the compiler use scalar loads (s_load) for the poses.
+typedef const __attribute__((address_space(4))) Job *JobCP;
+
+// Opaque copy of a uniform pointer.  Loads through the result cannot be hoisted above this
+// point, so the row loops re-issue their scalar loads (s_load from the scalar cache) every
+// iteration instead of keeping ~90 pose / intrinsics values live and spilling SGPRs into VGPR
+// lanes (v_writelane / v_readlane), which cost 14 % of the VALU stream before.
+AMVS_DEV JobCP reload(JobCP p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// (Non-temporal hints on the streaming state were measured without effect on MI355X -- 31.8 vs 31.7
+// G px-hyp/s -- and are not used.)
+
+// contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
+AMVS_DEV int xcd_remap(int bid, int nblk)
+{
+    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// per-row validity bits of the last K/2+1 rows packed into one (or two) registers
+template <int K, int S> struct Hist {
+    typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;
+};
+
+// Normal update of `n` queued refinement winners (entries head .. head+n-1 of the ring `nq`), one
+// per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).
+AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *n_out, float normal_range)
+{
+    if (lane < n) {
+        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
+        float *np = n_out + 3ll * (int)e.x;
+        float g0, g1, g2;
+        rng_normals3(e.y, g0, g1, g2);
+        float cn0 = np[0] + g0 * normal_range;
+        float cn1 = np[1] + g1 * normal_range;
+        float cn2 = np[2] + g2 * normal_range;
+        normalize3(cn0, cn1, cn2);
+        np[0] = cn0; np[1] = cn1; np[2] = cn2;
+    }
+}
+
+// AMVS_WG_WAVES horizontally adjacent strips share one workgroup (one CU, started together) and
+// re-align with a barrier every AMVS_WG_SYNC_ROWS rows: x-neighbours sample overlapping epipolar
+// bands of the sources, and they only share those lines in L1 / L2 while they work on the same rows.
+// Four waves (one per SIMD, so the workgroup granularity costs no occupancy) re-aligned every 8 rows
+// measured +1.8 % over single-wave workgroups (39.5 vs 38.85 G px-hyp/s; 16 rows the same, no
+// barrier +0.5 %).  With 10 waves the HBM-side traffic halves -- and the launch
+// gets slower, because a 5- or 10-wave workgroup fits only twice / once per CU.
+#ifndef AMVS_WG_WAVES
+#define AMVS_WG_WAVES 4
+#endif
+#ifndef AMVS_WG_SYNC_ROWS
+#define AMVS_WG_SYNC_ROWS 8
+#endif
+#if defined(AMVS_HSUM_LDS) && AMVS_WG_WAVES > 1
+#error "the LDS horizontal-sum variant keeps one exchange buffer per workgroup: build it with -DAMVS_WG_WAVES=1"
+#endif
+
+}  // namespace amvs

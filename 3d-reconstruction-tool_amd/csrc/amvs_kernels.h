@@ -17,6 +17,15 @@ struct alignas(64) SrcEntry {
     unsigned long long gray;    // float32 gray map
 };
 
+// Fast (tolerance) mode: the chain back-project -> world -> source camera -> pixel of
+// mvs_patchmatch.py:341-360 precomposed per (reference, source) pair in double on the host:
+//   [u z, v z, z]^T = d * (M [x, y, 1]^T) + b,  M = K R_s R_ref^T K^-1,  b = K (t_s - R_s R_ref^T t_ref)
+struct alignas(64) FastSrc {
+    float M[9], b[3];
+    unsigned long long pairs;   // first element of the zero-bordered packed map
+    unsigned long long pad_;
+};
+
 // One reference view of a batch: its pose, its source views and where its state lives.
 struct alignas(64) Job {
     float K[9], Kinv[9];    // shared intrinsics, copied per job so that the kernels fetch them with
@@ -27,7 +36,9 @@ struct alignas(64) Job {
     int slot;               // state / output slot inside the batch buffers
     int n_src;
     unsigned long long ref_pairs;   // image pixel (0,0) of the reference view's packed map
+    unsigned long long ref_stats;   // fast mode: float2 (mean1, var1) map of the reference view
     SrcEntry src[AMVS_KMAX_SRC];
+    FastSrc fsrc[AMVS_KMAX_SRC];    // fast mode
 };
 
 enum Mode { MODE_EVAL = 0, MODE_PROP = 1, MODE_REFINE = 2, MODE_CONF = 3 };
@@ -38,6 +49,7 @@ struct StepArgsBase {
     const float *images;                     // float32 gray maps [n_views][img_stride]
     const uint16_t *pairs;                   // packed 8-bit row-pair maps [n_views][pair_stride], or NULL
     long long pair_stride;
+    int fast;                                // 1: fast (tolerance) arithmetic; needs `pairs`
 };
 
 struct StepArgs : StepArgsBase {
@@ -77,6 +89,22 @@ int strip_out_width(int K);
 int step_waves_per_cu(int K, int S, bool u8);
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
+// amvs_kernels_fast.hip: the same steps in the fast arithmetic (a.fast != 0; launch_step /
+// launch_sweep forward to these)
+hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st);
+hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st);
+int step_fast_waves_per_cu(int K, int S);
+// test hook: per-source samples [S][H*W] and validity bits [H*W] of job 0 at the depth map a.d_in;
+// a.TH carries k/2, a.mode selects the bounds (MODE_EVAL patch bounds, MODE_CONF image bounds,
+// MODE_EVAL + 100 depth test only = plane sweep)
+hipError_t launch_sample_dump(int S, const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st);
+hipError_t launch_sample_dump_fast(int S, const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st);
+// (mean1, var1) of one view under the k x k zero-padded box filter from its packed 8-bit map:
+// exact integer window sums, statistics in gray units (float2 per pixel)
+hipError_t launch_fast_stats(int K, const uint16_t *pairs_view, int H, int W, float2 *out, hipStream_t st);
+// the double-precision composition of FastSrc::M / b
+void fast_compose(const float K[9], const float Rr[9], const float tr[3], const float Rs[9], const float ts[3],
+                  float M[9], float b[3]);
 hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st);
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,
                             int first_img, int n_img, float *mean_out, float *var_out,

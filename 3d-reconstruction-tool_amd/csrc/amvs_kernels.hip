@@ -17,37 +17,9 @@
 //     buffers "in" and writes buffers "out", so strips never see half-updated maps.
 //   * block index -> strip mapping is XCD-aware: each of the 8 XCDs receives a contiguous
 //     range of strips so halos and source-image rows are shared in that XCD's L2.
-#include "amvs_kernels.h"
-#include "amvs_device.h"
-
-#include <type_traits>
+#include "amvs_kernel_common.h"
 
 namespace amvs {
-
-// The job table is never written while a sweep kernel runs: reading it through the
-// constant address space lets the compiler use scalar loads (s_load) for the poses.
-typedef const __attribute__((address_space(4))) Job *JobCP;
-
-// Opaque copy of a uniform pointer.  Loads through the result cannot be hoisted above this
-// point, so the row loops re-issue their scalar loads (s_load from the scalar cache) every
-// iteration instead of keeping ~90 pose / intrinsics values live and spilling SGPRs into VGPR
-// lanes (v_writelane / v_readlane), which cost 14 % of the VALU stream before.
-AMVS_DEV JobCP reload(JobCP p)
-{
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
-// (Non-temporal hints on the streaming state were measured without effect on MI355X -- 31.8 vs 31.7
-// G px-hyp/s -- and are not used.)
-
-// contiguous strip ranges per XCD (blocks are dealt round-robin to XCDs); bijective
-AMVS_DEV int xcd_remap(int bid, int nblk)
-{
-    int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (bid >> 3);
-}
 
 // Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
 // (1) or after every operation / source (0, measured 2 % faster there).  The plane sweep always
@@ -161,11 +133,6 @@ template <int S> struct Ring {
     static constexpr int NL = AMVS_RING_LDS_SOURCES < S ? AMVS_RING_LDS_SOURCES : S;   // sources in LDS
     static constexpr int NR = S - NL > 0 ? S - NL : 1;                                  // register rings (>=1 for the type)
     static constexpr bool REF_IN_LDS = NL > 0;
-};
-
-// per-row validity bits of the last K/2+1 rows packed into one (or two) registers
-template <int K, int S> struct Hist {
-    typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;
 };
 
 template <int K, int S>
@@ -303,40 +270,6 @@ constexpr int min_waves(int K, int S)
 {
     return ((S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_MIN_WAVES_BIAS;
 }
-
-// Normal update of `n` queued refinement winners (entries head .. head+n-1 of the ring `nq`), one
-// per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).
-AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *n_out, float normal_range)
-{
-    if (lane < n) {
-        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
-        float *np = n_out + 3ll * (int)e.x;
-        float g0, g1, g2;
-        rng_normals3(e.y, g0, g1, g2);
-        float cn0 = np[0] + g0 * normal_range;
-        float cn1 = np[1] + g1 * normal_range;
-        float cn2 = np[2] + g2 * normal_range;
-        normalize3(cn0, cn1, cn2);
-        np[0] = cn0; np[1] = cn1; np[2] = cn2;
-    }
-}
-
-// AMVS_WG_WAVES horizontally adjacent strips share one workgroup (one CU, started together) and
-// re-align with a barrier every AMVS_WG_SYNC_ROWS rows: x-neighbours sample overlapping epipolar
-// bands of the sources, and they only share those lines in L1 / L2 while they work on the same rows.
-// Four waves (one per SIMD, so the workgroup granularity costs no occupancy) re-aligned every 8 rows
-// measured +1.8 % over single-wave workgroups (39.5 vs 38.85 G px-hyp/s; 16 rows the same, no
-// barrier +0.5 %).  With 10 waves the HBM-side traffic halves -- and the launch
-// gets slower, because a 5- or 10-wave workgroup fits only twice / once per CU.
-#ifndef AMVS_WG_WAVES
-#define AMVS_WG_WAVES 4
-#endif
-#ifndef AMVS_WG_SYNC_ROWS
-#define AMVS_WG_SYNC_ROWS 8
-#endif
-#if defined(AMVS_HSUM_LDS) && AMVS_WG_WAVES > 1
-#error "the LDS horizontal-sum variant keeps one exchange buffer per workgroup: build it with -DAMVS_WG_WAVES=1"
-#endif
 
 // MODE_T: MODE_PROP / MODE_REFINE are compiled as their own kernels (99 % of the launches: the mode
 // switches, the other modes' code and, for propagation steps, the whole RNG hash fall away at
@@ -621,6 +554,61 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 // view (every pixel exactly once, no strip halo, no rings): candidate depth, back-projection, the S
 // projections / gathers / bilinear samples.  Writes the samples ([pixel][S] float32), the candidate
 // depth and the validity bits for a window / NCC / select kernel to stream.
+
+// ------------------------------------------------------------------ sample dump ---
+// Test hook (amvs_sample_sources): the bilinear sample of every pixel in every source at the
+// pixel's own depth (mvs_patchmatch.py:341-377) and the validity bits -- the stage before the box
+// filter, which the tests' CPU checker reproduces bit for bit against torch-CPU's grid_sample.
+template <int S, bool U8>
+__global__ __launch_bounds__(AMVS_WAVE) void sample_dump_kernel(const StepArgs a, float *__restrict__ out,
+                                                                unsigned char *__restrict__ valid_out)
+{
+    __shared__ float lut[256];
+    const int lane = threadIdx.x;
+    if (U8) fill_gray_lut(lut, lane);
+    const JobCP job = (JobCP)a.jobs;
+    const int H = a.H, W = a.W, half = a.TH;                       // TH carries k/2 here
+    const bool conf = a.mode == MODE_CONF, nobounds = a.mode == MODE_EVAL + 100;
+    const float inf = __builtin_inff();
+    const SampleConsts sc = make_sample_consts(H, W, nobounds ? -inf : (conf ? 0.0f : (float)half),
+                                               nobounds ? inf : (conf ? (float)W : (float)(W - half)),
+                                               nobounds ? inf : (conf ? (float)H : (float)(H - half)));
+    const long long HW = (long long)H * W;
+    const int x = blockIdx.x * AMVS_WAVE + lane, y = blockIdx.y;
+    const bool live = x < W;
+    const float d = a.d_in[live ? y * W + x : 0];
+    JobCP jr = reload(job);
+    const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, x, y, d);
+    float v[S];
+    const unsigned okbits = sample_sources_checked<S, U8, true>(jr, a, sc, lut, Pw, live, v);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) out[s * HW + y * W + x] = v[s];
+        valid_out[y * W + x] = (unsigned char)okbits;
+    }
+}
+
+template <int S>
+static hipError_t launch_sample_dump_s(const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st)
+{
+    const dim3 grid((a.W + AMVS_WAVE - 1) / AMVS_WAVE, a.H), blk(AMVS_WAVE);
+    if (a.pairs) hipLaunchKernelGGL((sample_dump_kernel<S, true>), grid, blk, 0, st, a, out, valid_out);
+    else hipLaunchKernelGGL((sample_dump_kernel<S, false>), grid, blk, 0, st, a, out, valid_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_dump(int S, const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st)
+{
+    if (a.fast) return launch_sample_dump_fast(S, a, out, valid_out, st);
+    switch (S) {
+    case 2: return launch_sample_dump_s<2>(a, out, valid_out, st);
+    case 3: return launch_sample_dump_s<3>(a, out, valid_out, st);
+    case 4: return launch_sample_dump_s<4>(a, out, valid_out, st);
+    case 5: return launch_sample_dump_s<5>(a, out, valid_out, st);
+    case 6: return launch_sample_dump_s<6>(a, out, valid_out, st);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 // ------------------------------------------------------------------ plane sweep --
 // _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
@@ -1004,6 +992,7 @@ int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 {
+    if (a.fast) return launch_step_fast(K, S, a, st);
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
     switch (K) {
     case 3: AMVS_FOR_S(3, launch_step_ks, a, nblk, st)
@@ -1017,6 +1006,7 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
 {
+    if (a.fast) return launch_sweep_fast(K, S, a, st);
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
     switch (K) {
     case 3: AMVS_FOR_S(3, launch_sweep_ks, a, nblk, st)

@@ -1,0 +1,775 @@
+// amvs_kernels_fast.hip -- the sweep kernels in the FAST (tolerance) arithmetic, AMVS_MODE_FAST.
+//
+// Same algorithm, same execution shape and same RNG / candidate / select logic as
+// amvs_kernels.hip (reference: src/core/mvs_patchmatch.py:323-534, src/core/dense_stereo.py:
+// 262-310); what changes is the arithmetic of one cost evaluation, which no longer reproduces
+// ATen's float32 operation sequence bit for bit but stays within the tolerances stated in
+// DESIGN.md (and is itself restated operation for operation by the tests' CPU checker, so these
+// kernels are still verified BIT-EXACTLY, against that restatement's fast mode):
+//   * projection precomposed per (reference, source) pair on the host (FastSrc, amvs_kernels.h):
+//     [u z, v z, z] = d * (M [x,y,1]) + b  -- 6 + 3 FMAs instead of two 3x3 rotations, two
+//     translations and the intrinsics; one reciprocal of z; no Markstein quotient refinement; no
+//     normalise / un-normalise round trip around grid_sample (mvs_patchmatch.py:367-377);
+//   * validity u in [lo, W-lo) as ONE unsigned compare of the bit pattern of u - lo;
+//   * the four codes of a footprint are converted with v_cvt_f32_ubyte{0..3} (no LDS table) and
+//     interpolated as two horizontal lerps + one vertical lerp; all window sums run in code units
+//     (0..255), the 1/255 and 1/k^2 factors are folded into two constants of the NCC epilogue;
+//   * the reference image's window sums are exact integers, precomputed once per view and patch
+//     size as (mean1, var1) maps (launch_fast_stats): no ref sums, and no ref ring in LDS -- the
+//     last k reference codes of a column travel as packed bytes in 2-3 VGPRs;
+//   * NCC epilogue: cov * RN(1/den) (no quotient refinement).
+#include "amvs_kernel_common.h"
+
+namespace amvs {
+
+// sources whose vertical ring lives in LDS (the others in shifting register rings)
+#ifndef AMVS_FAST_RING_LDS
+#define AMVS_FAST_RING_LDS 3
+#endif
+// sources sharing one opaque job-pointer copy (scheduling barrier): their geometry may interleave
+#ifndef AMVS_FAST_RELOAD_STRIDE
+#define AMVS_FAST_RELOAD_STRIDE 2
+#endif
+#ifndef AMVS_FAST_MIN_WAVES_BIAS
+#define AMVS_FAST_MIN_WAVES_BIAS 0
+#endif
+
+template <int S> struct FRing {
+    static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
+    static constexpr int NR = S - NL > 0 ? S - NL : 1;
+};
+
+// the last K reference codes of a lane's column as packed bytes: the window occupies the TOP K
+// bytes of NB dwords (oldest first)
+template <int K> struct RefBytes {
+    static constexpr int NB = (K + 3) / 4;
+    static constexpr int FIRST = 4 * NB - K;       // byte index of the oldest window entry
+};
+
+template <int K>
+AMVS_DEV void ref_bytes_push(uint32_t (&rb)[RefBytes<K>::NB], uint32_t code)
+{
+    constexpr int NB = RefBytes<K>::NB;
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) rb[i] = __builtin_amdgcn_alignbyte(rb[i + 1], rb[i], 1);
+    rb[NB - 1] = __builtin_amdgcn_alignbyte(code, rb[NB - 1], 1);
+}
+
+template <int K>
+AMVS_DEV float ref_bytes_get(const uint32_t (&rb)[RefBytes<K>::NB], int i)
+{
+    const int j = RefBytes<K>::FIRST + i;
+    return (float)((rb[j >> 2] >> (8 * (j & 3))) & 0xFFu);          // v_cvt_f32_ubyteN
+}
+
+// wave-uniform constants of the fast sampler
+struct FastConsts {
+    float flo;                    // lower validity bound lo (patch half, or 0 for the confidence pass)
+    uint32_t rxb, ryb;            // bit patterns of (float)(W - 2 lo), (float)(H - 2 lo)
+    float cl_lo, cl_hix, cl_hiy;  // clamp of the footprint origin in (u - lo, v - lo) coordinates
+    int pitch2;                   // bytes per row of the padded map
+    int addc2;                    // byte offset of footprint origin (-(B+lo), -(B+lo)) ... see fast_geom
+};
+
+AMVS_DEV FastConsts make_fast_consts(int H, int W, int lo)
+{
+    constexpr int B = AMVS_PAIR_BORDER;
+    FastConsts c;
+    c.flo = uniform_f((float)lo);
+    c.rxb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((float)(W - 2 * lo)));
+    c.ryb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((float)(H - 2 * lo)));
+    c.cl_lo = uniform_f(-(float)(B + lo));
+    c.cl_hix = uniform_f((float)(W - lo));
+    c.cl_hiy = uniform_f((float)(H - lo));
+    c.pitch2 = 2 * (W + 2 * B);
+    c.addc2 = 2 * (lo + B) * (W + 2 * B + 1);
+    return c;
+}
+
+struct FastTap { float wx, wy; int off; };
+
+// Projection of one pixel into one source (see the file header): weights, byte offset of the
+// footprint's dword, validity.  LEAN: v_rcp_f32 + one FMA correction == 1.0f / zz wherever
+// 2^-95 <= |zz| < 2^96 (amvs_device.h, verified exhaustively); the caller collects min / max |zz|
+// over the sources and repeats the row with LEAN = false if a lane left that range.
+template <bool LEAN, bool BOUNDED, class MP, class BP>
+AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, float fx, float fy, float d, bool &valid,
+                           float &zlo, float &zhi)
+{
+    const float q0 = __builtin_fmaf(M[1], fy, __builtin_fmaf(M[0], fx, M[2]));
+    const float q1 = __builtin_fmaf(M[4], fy, __builtin_fmaf(M[3], fx, M[5]));
+    const float q2 = __builtin_fmaf(M[7], fy, __builtin_fmaf(M[6], fx, M[8]));
+    const float p0 = __builtin_fmaf(d, q0, b[0]);
+    const float p1 = __builtin_fmaf(d, q1, b[1]);
+    const float p2 = __builtin_fmaf(d, q2, b[2]);
+    const float zz = p2 + 1e-8f;
+    float rz;
+    if constexpr (LEAN) {
+        rz = __builtin_amdgcn_rcpf(zz);
+        rz = __builtin_fmaf(rz, __builtin_fmaf(-zz, rz, 1.0f), rz);
+        const float az = __builtin_fabsf(zz);
+        zlo = __builtin_fminf(zlo, az);
+        zhi = __builtin_fmaxf(zhi, az);
+    } else {
+        rz = 1.0f / zz;
+    }
+    const float up = __builtin_fmaf(p0, rz, -fc.flo);
+    const float vp = __builtin_fmaf(p1, rz, -fc.flo);
+    valid = p2 > 0.1f;
+    if constexpr (BOUNDED) {
+        // non-short-circuit: '&&' makes hipcc emit a branch per source here
+        const bool uin = __float_as_uint(up) < fc.rxb, vin = __float_as_uint(vp) < fc.ryb;
+        valid = (bool)((int)valid & (int)uin & (int)vin);
+    }
+    const float x0 = __builtin_floorf(up), y0 = __builtin_floorf(vp);
+    FastTap t;
+    t.wx = up - x0;
+    t.wy = vp - y0;
+    // footprint origin clamped into the zero border (true coordinates [-2, W] x [-2, H]); v_med3_f32
+    // maps a NaN to the lower bound
+    const int xi = (int)__builtin_amdgcn_fmed3f(x0, fc.cl_lo, fc.cl_hix);
+    const int yi = (int)__builtin_amdgcn_fmed3f(y0, fc.cl_lo, fc.cl_hiy);
+    // byte offset from the first element of the padded map: ((yi+lo+B) * pitch + xi+lo+B) * 2 >= 0
+    t.off = __mul24(yi, fc.pitch2) + fc.addc2 + (xi << 1);
+    return t;
+}
+
+AMVS_DEV uint32_t fast_load(unsigned long long img, int off)
+{
+    uint32_t w;
+    __builtin_memcpy(&w, (GlobalBytes)img + (unsigned long long)(unsigned)off, 4);
+    return w;
+}
+
+// bytes of the dword: (y,x) (y+1,x) (y,x+1) (y+1,x+1); two horizontal lerps, one vertical
+AMVS_DEV float fast_finish(uint32_t w, const FastTap &t, bool live)
+{
+    const float t00 = (float)(w & 0xFFu), t10 = (float)((w >> 8) & 0xFFu);
+    const float t01 = (float)((w >> 16) & 0xFFu), t11 = (float)(w >> 24);
+    const float top = __builtin_fmaf(t.wx, t01 - t00, t00);
+    const float bot = __builtin_fmaf(t.wx, t11 - t10, t10);
+    const float v = __builtin_fmaf(t.wy, bot - top, top);
+    return live ? v : 0.0f;
+}
+
+template <int S, bool LEAN, bool BOUNDED>
+AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, float fx, float fy, float d, bool live,
+                                      float (&v)[S], bool &ok)
+{
+    unsigned okbits = 0u;
+    FastTap tg[S];
+    uint32_t raw[S];
+    float zlo = 1.0f, zhi = 1.0f;
+    JobCP jr = job;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s % AMVS_FAST_RELOAD_STRIDE == 0) jr = reload(jr);
+        float M[9], b[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = jr->fsrc[s].M[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = jr->fsrc[s].b[i];
+        const unsigned long long img = jr->fsrc[s].pairs;
+        bool valid;
+        tg[s] = fast_geom<LEAN, BOUNDED>(M, b, fc, fx, fy, d, valid, zlo, zhi);
+        okbits |= valid ? (1u << s) : 0u;
+        raw[s] = fast_load(img, tg[s].off);
+    }
+    if constexpr (LEAN) ok = (zlo >= 0x1p-95f) & (zhi < 0x1p96f);
+#pragma unroll
+    for (int s = 0; s < S; ++s) v[s] = fast_finish(raw[s], tg[s], live);
+    return okbits;
+}
+
+// optimistic lean reciprocals first, IEEE repeat if some lane's z left the verified range
+template <int S, bool BOUNDED>
+AMVS_DEV unsigned fast_sample_sources_checked(JobCP job, const FastConsts &fc, float fx, float fy, float d,
+                                              bool live, float (&v)[S])
+{
+    bool ok = true;
+    unsigned okbits = fast_sample_sources<S, true, BOUNDED>(job, fc, fx, fy, d, live, v, ok);
+    if (__builtin_expect(!__all(ok), 0))
+        okbits = fast_sample_sources<S, false, BOUNDED>(reload(job), fc, fx, fy, d, live, v, ok);
+    return okbits;
+}
+
+template <int K, int S>
+AMVS_DEV void fring_push(float *lring, int lane, int wslot, float (&ring_v)[FRing<S>::NR][K], const float (&v)[S])
+{
+    constexpr int NL = FRing<S>::NL;
+#pragma unroll
+    for (int s = 0; s < NL; ++s) lring[(s * K + wslot) * AMVS_WAVE + lane] = v[s];
+#pragma unroll
+    for (int s = NL; s < S; ++s) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring_v[s - NL][i] = ring_v[s - NL][i + 1];
+        ring_v[s - NL][K - 1] = v[s];
+    }
+}
+
+// k x k window sums of v, v*v and r*v (code units) for S sources: column sums top -> bottom (plain
+// sum for v, FMA chains for v*v and r*v), row sums right -> left as K-1 DPP wave shifts -- the
+// order of the exact kernels (and of the tests' CPU checker).
+template <int K, int S>
+AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr)[K],
+                               const float (&ring_v)[FRing<S>::NR][K], int lane,
+                               float (&bv)[S], float (&bvv)[S], float (&brv)[S])
+{
+    constexpr int NL = FRing<S>::NL;
+    int slot[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) slot[i] = oldest + i >= K ? oldest + i - K : oldest + i;
+    float cs[3 * S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float vv[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            vv[i] = s < NL ? lring[(s * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][i];
+        float cv = vv[0];
+        float cvv = vv[0] * vv[0];
+        float crv = rr[0] * vv[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) {
+            cv = cv + vv[i];
+            cvv = __builtin_fmaf(vv[i], vv[i], cvv);
+            crv = __builtin_fmaf(rr[i], vv[i], crv);
+        }
+        cs[3 * s] = cv; cs[3 * s + 1] = cvv; cs[3 * s + 2] = crv;
+    }
+    float acc[3 * S];
+#pragma unroll
+    for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
+#pragma unroll
+    for (int j = 1; j < K; ++j)
+#pragma unroll
+        for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
+#pragma unroll
+    for (int s = 0; s < S; ++s) { bv[s] = acc[3 * s]; bvv[s] = acc[3 * s + 1]; brv[s] = acc[3 * s + 2]; }
+}
+
+constexpr int fast_min_waves(int K, int S)
+{
+    return ((S + 1) * K <= 40 ? 5 : ((S + 1) * K <= 60 ? 4 : 3)) + AMVS_FAST_MIN_WAVES_BIAS;
+}
+
+// ------------------------------------------------------------------ sweep step ---
+template <int K, int S, int MODE_T>
+__global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) void pm_step_fast_kernel(const StepArgs a)
+{
+    constexpr int HALF = K / 2;
+    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
+    constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));      // 1 / (k^2 * 255)
+    constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));    // 1 / (k^2 * 255^2)
+    constexpr int NL = FRing<S>::NL;
+    __shared__ float lring_all[AMVS_WG_WAVES * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
+    constexpr int NQ = 2 * AMVS_WAVE;
+    __shared__ uint2 nq_all[AMVS_WG_WAVES * NQ];
+
+    const int lane = threadIdx.x & (AMVS_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
+    float *lring = lring_all + wv * ((NL > 0 ? NL : 1) * K * AMVS_WAVE);
+    uint2 *nq = nq_all + wv * NQ;
+    int q_head = 0, q_tail = 0;
+    const int tiles_per_job = a.tiles_x * a.tiles_y;
+    const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
+    if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
+    const int job_id = t / tiles_per_job;
+    const int rem = t - job_id * tiles_per_job;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+
+    const JobCP job = (JobCP)(a.jobs + job_id);
+    const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
+    const long long HW = (long long)H * W;
+    constexpr int PADW = 2 * AMVS_PAIR_BORDER;
+    const uint16_t *__restrict__ ref_pairs = (const uint16_t *)job->ref_pairs;
+    const float2 *__restrict__ ref_stats = (const float2 *)job->ref_stats;
+    const float *__restrict__ d_in = a.d_in + job->slot * HW;
+    const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
+    float *__restrict__ d_out = a.d_out + job->slot * HW;
+    float *cost_io = a.cost + job->slot * HW;
+    float *n_out = a.n_out + job->slot * HW * 3;
+    float *__restrict__ aux = a.aux + job->slot * HW;
+
+    const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
+    // validity window of the projection: patch bounds (mvs_patchmatch.py:362-363) or image bounds
+    // for the confidence pass (:516-517)
+    const FastConsts fc = make_fast_consts(H, W, mode == MODE_CONF ? 0 : HALF);
+
+    const int xbase = tx * OUTW - HALF;
+    const int y0 = ty * a.TH;
+    const int xr = xbase + lane;
+    const float fx = (float)xr;
+    const bool col_in = (unsigned)xr < (unsigned)W;
+    const int rows = min(a.TH, H - y0) + 2 * HALF;
+
+    uint32_t rb[RefBytes<K>::NB];
+    float ring_v[FRing<S>::NR][K];
+    typename Hist<K, S>::T hist_ok = 0;
+    uint32_t hist_h0[HALF + 1];
+#pragma unroll
+    for (int i = 0; i < RefBytes<K>::NB; ++i) rb[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int s = 0; s < FRing<S>::NR; ++s) ring_v[s][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i <= HALF; ++i) hist_h0[i] = 0u;
+    int wslot = 0;
+
+    const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
+    const int noff = oy * W + ox;
+
+    for (int r = 0; r < rows; ++r) {
+#if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
+        if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
+#endif
+        const int yr = y0 - HALF + r;
+        const bool live = col_in & ((unsigned)yr < (unsigned)H);
+        const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
+        const int pix = yr * W + xr;
+        const float d_raw = d_in[inb ? pix + noff : 0];
+        const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
+
+        // ---- candidate depth of this (possibly halo) pixel: as in the exact kernel ----
+        float dc = inb ? d_raw : a.depth_min;
+        const uint32_t h0 = pixel_hash((uint32_t)pix, key);
+        {
+            float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
+            float d = dc + delta;
+            d = d < a.depth_min ? a.depth_min : d;
+            d = d > a.depth_max ? a.depth_max : d;
+            dc = mode == MODE_REFINE ? d : dc;
+        }
+        const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
+
+        float v[S];
+        const unsigned okbits = fast_sample_sources_checked<S, true>(job, fc, fx, (float)yr, dc, live, v);
+
+        // ---- push into the vertical rings ----
+        ref_bytes_push<K>(rb, rcode);
+        fring_push<K, S>(lring, lane, wslot, ring_v, v);
+        wslot = wslot + 1 == K ? 0 : wslot + 1;
+        hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
+        hist_h0[HALF] = h0;
+
+        if (r < 2 * HALF) continue;
+
+        // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
+        const int yc = yr - HALF;
+        const int xc = xr + HALF;
+        const bool outl = (lane < OUTW) & (xc < W);
+        const int pc = outl ? yc * W + xc : 0;
+        const float oldd = d_in[pc], oldc = cost_io[pc];
+        const float2 mv1 = ref_stats[pc];
+        const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
+        const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
+
+        float rr[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) rr[i] = ref_bytes_get<K>(rb, i);
+        float bvs[S], bvvs[S], brvs[S];
+        window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
+        const float m1 = mv1.x, v1 = mv1.y;
+
+        float total = 0.0f, cnt = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            // _ncc_cost (mvs_patchmatch.py:403-411), sums in code units
+            const float mean2 = bvs[s] * C1;
+            const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
+            const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
+            float den, rden;
+            ncc_denominator(v1 * var2, den, rden);
+            const float cost = 1.0f - cov * rden;
+            const bool oks = (okc >> s) & 1u;
+            const float ncc2 = 1.0f - cost;                         // :530
+            const bool hit = mode == MODE_CONF ? (oks & (ncc2 > 0.6f)) : oks;
+            total = (hit & (mode != MODE_CONF)) ? total + cost : total;
+            cnt = hit ? cnt + 1.0f : cnt;
+        }
+        const bool act = outl;
+
+        if (mode == MODE_CONF) {
+            if (act) aux[pc] = cnt;
+            continue;
+        }
+
+        // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
+        const float cden = cnt + 1e-8f;
+        bool cden_ok = true;
+        const float avg = total * rcp_t<true>(cden, cden_ok);
+        const float newc = cnt >= 2.0f ? avg : __builtin_inff();
+        if (mode == MODE_EVAL) {
+            if (act) aux[pc] = newc;
+            continue;
+        }
+
+        // ---- select (mvs_patchmatch.py:452-455 / :486-489): as in the exact kernel ----
+        const bool better = act & (newc < oldc);
+        if (better) cost_io[pc] = newc;
+        if (mode == MODE_PROP) {
+            const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
+            const int pn = inb_c ? pc + noff : 0;
+            const int ps = better ? pn : pc;
+            const float nb_d = d_in[pn];
+            float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
+            const bool zero = better & !inb_c;
+            if (act) {
+                d_out[pc] = better ? (inb_c ? nb_d : a.depth_min) : oldd;
+                n_out[3 * pc] = zero ? 0.0f : t0;
+                n_out[3 * pc + 1] = zero ? 0.0f : t1;
+                n_out[3 * pc + 2] = zero ? 0.0f : t2;
+            }
+        } else {
+            float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
+            float d = oldd + delta;
+            d = d < a.depth_min ? a.depth_min : d;
+            d = d > a.depth_max ? a.depth_max : d;
+            if (act) d_out[pc] = better ? d : oldd;
+            const unsigned long long won = __ballot(better);
+            if (won != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
+                q_tail += __popcll(won);
+                if (q_tail - q_head >= AMVS_WAVE) {
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
+                    q_head += AMVS_WAVE;
+                }
+            }
+        }
+    }
+    if (mode == MODE_REFINE) {
+        while (q_tail - q_head > 0) {
+            const int n = min(q_tail - q_head, AMVS_WAVE);
+            refine_normals(nq, q_head, n, lane, n_out, a.normal_range);
+            q_head += n;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ plane sweep --
+// _plane_sweep_torch (dense_stereo.py:262-310) in the fast arithmetic; structure (strips, plane
+// chunks, 16-bit running-best keys in LDS, atomicMax merge) as plane_sweep_kernel.
+template <int K, int S>
+__global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const SweepArgs a)
+{
+    constexpr int HALF = K / 2;
+    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
+    constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));
+    constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));
+    constexpr int NL = FRing<S>::NL;
+    __shared__ uint16_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
+    __shared__ float lring[(NL > 0 ? NL : 1) * K * AMVS_WAVE];
+
+    const int lane = threadIdx.x;
+    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+    const int cid = t0 % a.n_chunks;
+    const int t = t0 / a.n_chunks;
+    const int tiles_per_job = a.tiles_x * a.tiles_y;
+    const int job_id = t / tiles_per_job;
+    const int rem = t - job_id * tiles_per_job;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+    const int d_begin = cid * a.chunk, d_end = min(a.D, d_begin + a.chunk);
+
+    const JobCP job = (JobCP)(a.jobs + job_id);
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+    constexpr int PADW = 2 * AMVS_PAIR_BORDER;
+    const uint16_t *__restrict__ ref_pairs = (const uint16_t *)job->ref_pairs;
+    const float2 *__restrict__ ref_stats = (const float2 *)job->ref_stats;
+    const FastConsts fc = make_fast_consts(H, W, 0);
+
+    const int xbase = tx * OUTW - HALF;
+    const int y0 = ty * a.TH;
+    const int xr = xbase + lane;
+    const float fx = (float)xr;
+    const bool col_in = (unsigned)xr < (unsigned)W;
+    const int trows = min(a.TH, H - y0);
+    const int rows = trows + 2 * HALF;
+
+    for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
+
+    for (int d = d_begin; d < d_end; ++d) {
+        const float depth = a.depths[d];
+        uint32_t rb[RefBytes<K>::NB];
+        float ring_v[FRing<S>::NR][K];
+        typename Hist<K, S>::T hist_ok = 0;
+#pragma unroll
+        for (int i = 0; i < RefBytes<K>::NB; ++i) rb[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+            for (int s = 0; s < FRing<S>::NR; ++s) ring_v[s][i] = 0.0f;
+        int wslot = 0;
+
+        for (int r = 0; r < rows; ++r) {
+            const int yr = y0 - HALF + r;
+            const bool live = col_in & ((unsigned)yr < (unsigned)H);
+            const int pix = yr * W + xr;
+            const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
+            const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
+            float v[S];
+            const unsigned okbits = fast_sample_sources_checked<S, false>(job, fc, fx, (float)yr, depth, live, v);
+            ref_bytes_push<K>(rb, rcode);
+            fring_push<K, S>(lring, lane, wslot, ring_v, v);
+            wslot = wslot + 1 == K ? 0 : wslot + 1;
+            hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
+            if (r < 2 * HALF) continue;
+
+            const int yc = yr - HALF;
+            const int xc = xr + HALF;
+            const bool outl = (lane < OUTW) & (xc < W);
+            const float2 mv1 = ref_stats[outl ? yc * W + xc : 0];
+            const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
+            float rr[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) rr[i] = ref_bytes_get<K>(rb, i);
+            float bvs[S], bvvs[S], brvs[S];
+            window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
+            const float m1 = mv1.x, v1 = mv1.y;
+            uint32_t votes = 0u;
+            auto vote_stage = [&](auto lean, bool &ok) {
+                constexpr bool LEAN = decltype(lean)::value;
+                votes = 0u;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
+                    const float mean2 = bvs[s] * C1;
+                    const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
+                    const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
+                    const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
+                    const float ncc = cov * rcp_t<LEAN>(den, ok);
+                    if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+                }
+            };
+            {
+                bool ok = true;
+                vote_stage(std::true_type{}, ok);
+                if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
+            }
+            if (outl) {
+                const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
+                const uint32_t cur = best[yc - y0][lane];
+                if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
+            }
+        }
+    }
+
+    unsigned *__restrict__ keys = a.keys + job->slot * HW;
+    const int xc = xr + HALF;
+    if (lane < OUTW && xc < W)
+        for (int i = 0; i < trows; ++i) {
+            const uint32_t b = best[i][lane];
+            const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
+            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
+        }
+}
+
+// ------------------------------------------------------------------ sample dump ---
+// Test hook (amvs_sample_sources): the sampled value of every pixel in every source at the
+// pixel's own depth, in code units, and the validity bits -- the stage before the box filter.
+template <int S>
+__global__ __launch_bounds__(AMVS_WAVE) void sample_dump_fast_kernel(const StepArgs a, float *__restrict__ out,
+                                                                     unsigned char *__restrict__ valid_out)
+{
+    const JobCP job = (JobCP)a.jobs;
+    const int H = a.H, W = a.W;
+    const FastConsts fc = make_fast_consts(H, W, a.mode == MODE_CONF ? 0 : a.TH);   // TH carries k/2 here
+    const long long HW = (long long)H * W;
+    const int x = blockIdx.x * AMVS_WAVE + threadIdx.x, y = blockIdx.y;
+    const bool live = x < W;
+    const float d = a.d_in[live ? y * W + x : 0];
+    float v[S];
+    unsigned okbits;
+    if (a.mode == MODE_EVAL + 100) okbits = fast_sample_sources_checked<S, false>(job, fc, (float)x, (float)y, d, live, v);
+    else okbits = fast_sample_sources_checked<S, true>(job, fc, (float)x, (float)y, d, live, v);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) out[s * HW + y * W + x] = v[s];
+        valid_out[y * W + x] = (unsigned char)okbits;
+    }
+}
+
+template <int S>
+static hipError_t launch_sample_dump_fast_s(const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st)
+{
+    hipLaunchKernelGGL((sample_dump_fast_kernel<S>), dim3((a.W + AMVS_WAVE - 1) / AMVS_WAVE, a.H), dim3(AMVS_WAVE), 0, st,
+                       a, out, valid_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sample_dump_fast(int S, const StepArgs &a, float *out, unsigned char *valid_out, hipStream_t st)
+{
+    switch (S) {
+    case 2: return launch_sample_dump_fast_s<2>(a, out, valid_out, st);
+    case 3: return launch_sample_dump_fast_s<3>(a, out, valid_out, st);
+    case 4: return launch_sample_dump_fast_s<4>(a, out, valid_out, st);
+    case 5: return launch_sample_dump_fast_s<5>(a, out, valid_out, st);
+    case 6: return launch_sample_dump_fast_s<6>(a, out, valid_out, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------ ref stats ----
+// (mean1, var1) of mvs_patchmatch.py:403,406 from the 8-bit codes: exact integer window sums
+// (<= k^2 * 255^2 < 2^24), then mean1 = sum * C1, var1 = fma(-mean1, mean1, sumsq * C2).
+template <int K>
+__global__ __launch_bounds__(256) void fast_stats_kernel(const uint16_t *__restrict__ pairs, int H, int W,
+                                                         float2 *__restrict__ out)
+{
+    constexpr int HALF = K / 2, B = AMVS_PAIR_BORDER;
+    constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));
+    constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));
+    const int PW = W + 2 * B;
+    const long long n = (long long)H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        int sr = 0, srr = 0;
+        for (int dy = -HALF; dy <= HALF; ++dy) {
+            const int yy = y + dy;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dx = -HALF; dx <= HALF; ++dx) {
+                const int xx = x + dx;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const int c = pairs[(long long)(yy + B) * PW + xx + B] & 0xFF;
+                sr += c; srr += c * c;
+            }
+        }
+        const float m1 = (float)sr * C1;
+        out[i] = make_float2(m1, __builtin_fmaf(-m1, m1, (float)srr * C2));
+    }
+}
+
+hipError_t launch_fast_stats(int K, const uint16_t *pairs_view, int H, int W, float2 *out, hipStream_t st)
+{
+    const long long n = (long long)H * W;
+    const dim3 grid((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), blk(256);
+    switch (K) {
+    case 3: hipLaunchKernelGGL((fast_stats_kernel<3>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 5: hipLaunchKernelGGL((fast_stats_kernel<5>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 7: hipLaunchKernelGGL((fast_stats_kernel<7>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 9: hipLaunchKernelGGL((fast_stats_kernel<9>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 11: hipLaunchKernelGGL((fast_stats_kernel<11>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ host side ----
+// M = K R_s R_ref^T K^-1, b = K (t_s - R_s R_ref^T t_ref): double arithmetic on the float32
+// operands, sums left to right, K^-1 by cofactors, one rounding to float32 at the end.
+void fast_compose(const float K[9], const float Rr[9], const float tr[3], const float Rs[9], const float ts[3],
+                  float M[9], float b[3])
+{
+    double Kd[9], Ki[9], Rrel[9], trel[3], A[9];
+    for (int i = 0; i < 9; ++i) Kd[i] = (double)K[i];
+    const double det = Kd[0] * (Kd[4] * Kd[8] - Kd[5] * Kd[7]) - Kd[1] * (Kd[3] * Kd[8] - Kd[5] * Kd[6]) +
+                       Kd[2] * (Kd[3] * Kd[7] - Kd[4] * Kd[6]);
+    Ki[0] = (Kd[4] * Kd[8] - Kd[5] * Kd[7]) / det; Ki[1] = (Kd[2] * Kd[7] - Kd[1] * Kd[8]) / det;
+    Ki[2] = (Kd[1] * Kd[5] - Kd[2] * Kd[4]) / det; Ki[3] = (Kd[5] * Kd[6] - Kd[3] * Kd[8]) / det;
+    Ki[4] = (Kd[0] * Kd[8] - Kd[2] * Kd[6]) / det; Ki[5] = (Kd[2] * Kd[3] - Kd[0] * Kd[5]) / det;
+    Ki[6] = (Kd[3] * Kd[7] - Kd[4] * Kd[6]) / det; Ki[7] = (Kd[1] * Kd[6] - Kd[0] * Kd[7]) / det;
+    Ki[8] = (Kd[0] * Kd[4] - Kd[1] * Kd[3]) / det;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Rrel[3 * i + j] = ((double)Rs[3 * i] * (double)Rr[3 * j] + (double)Rs[3 * i + 1] * (double)Rr[3 * j + 1]) +
+                              (double)Rs[3 * i + 2] * (double)Rr[3 * j + 2];
+    for (int i = 0; i < 3; ++i)
+        trel[i] = (double)ts[i] - ((Rrel[3 * i] * (double)tr[0] + Rrel[3 * i + 1] * (double)tr[1]) +
+                                   Rrel[3 * i + 2] * (double)tr[2]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A[3 * i + j] = (Kd[3 * i] * Rrel[j] + Kd[3 * i + 1] * Rrel[3 + j]) + Kd[3 * i + 2] * Rrel[6 + j];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            M[3 * i + j] = (float)((A[3 * i] * Ki[j] + A[3 * i + 1] * Ki[3 + j]) + A[3 * i + 2] * Ki[6 + j]);
+        b[i] = (float)((Kd[3 * i] * trel[0] + Kd[3 * i + 1] * trel[1]) + Kd[3 * i + 2] * trel[2]);
+    }
+}
+
+// ------------------------------------------------------------------ dispatch -----
+template <int K, int S>
+static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t st)
+{
+    const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
+    const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
+    if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, 0, st, a);
+    else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+template <int K, int S>
+static hipError_t launch_sweep_fast_ks(const SweepArgs &a, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL((plane_sweep_fast_kernel<K, S>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int K, int S>
+static int step_fast_occupancy_ks()
+{
+    int n = 0;
+    constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB, 0);
+    return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
+}
+
+#define AMVS_FOR_S(K, FN, ...)                                      \
+    switch (S) {                                                    \
+    case 2: return FN<K, 2>(__VA_ARGS__);                           \
+    case 3: return FN<K, 3>(__VA_ARGS__);                           \
+    case 4: return FN<K, 4>(__VA_ARGS__);                           \
+    case 5: return FN<K, 5>(__VA_ARGS__);                           \
+    case 6: return FN<K, 6>(__VA_ARGS__);                           \
+    default: return decltype(FN<K, 2>(__VA_ARGS__))(1);             \
+    }
+
+int step_fast_waves_per_cu(int K, int S)
+{
+    switch (K) {
+    case 3: AMVS_FOR_S(3, step_fast_occupancy_ks)
+    case 5: AMVS_FOR_S(5, step_fast_occupancy_ks)
+    case 7: AMVS_FOR_S(7, step_fast_occupancy_ks)
+    case 9: AMVS_FOR_S(9, step_fast_occupancy_ks)
+    case 11: AMVS_FOR_S(11, step_fast_occupancy_ks)
+    default: return 8;
+    }
+}
+
+hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
+{
+    if (!a.pairs) return hipErrorInvalidValue;        // fast mode samples the packed 8-bit maps only
+    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
+    switch (K) {
+    case 3: AMVS_FOR_S(3, launch_step_fast_ks, a, nblk, st)
+    case 5: AMVS_FOR_S(5, launch_step_fast_ks, a, nblk, st)
+    case 7: AMVS_FOR_S(7, launch_step_fast_ks, a, nblk, st)
+    case 9: AMVS_FOR_S(9, launch_step_fast_ks, a, nblk, st)
+    case 11: AMVS_FOR_S(11, launch_step_fast_ks, a, nblk, st)
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st)
+{
+    if (!a.pairs) return hipErrorInvalidValue;
+    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
+    switch (K) {
+    case 3: AMVS_FOR_S(3, launch_sweep_fast_ks, a, nblk, st)
+    case 5: AMVS_FOR_S(5, launch_sweep_fast_ks, a, nblk, st)
+    case 7: AMVS_FOR_S(7, launch_sweep_fast_ks, a, nblk, st)
+    case 9: AMVS_FOR_S(9, launch_sweep_fast_ks, a, nblk, st)
+    case 11: AMVS_FOR_S(11, launch_sweep_fast_ks, a, nblk, st)
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace amvs

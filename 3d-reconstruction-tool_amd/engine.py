@@ -24,17 +24,18 @@ def _ids(a):
 
 
 def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0,
-                   views_per_launch=0):
-    """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does."""
+                   views_per_launch=0, mode="default"):
+    """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does.
+    mode: "default" (the engine's), "exact" or "fast" (include/amvs.h AMVS_MODE_*)."""
     log_min = np.log(float(depth_min))
     log_max = np.log(float(depth_max))
     return PmParams(int(patch_size), int(num_iterations), int(num_samples), int(tile_rows),
                     int(views_per_launch), float(depth_min), float(depth_max),
-                    float(np.float32(log_max - log_min)), float(np.float32(log_min)))
+                    float(np.float32(log_max - log_min)), float(np.float32(log_min)), _lib.MODES[mode])
 
 
 class Engine:
-    def __init__(self, H, W, n_views, K, K_inv=None, device=0):
+    def __init__(self, H, W, n_views, K, K_inv=None, device=0, mode="exact"):
         self._lib = _lib.load()
         self.H, self.W, self.n_views, self.device = int(H), int(W), int(n_views), int(device)
         self.K = _f32(np.asarray(K, np.float32).reshape(3, 3))
@@ -48,6 +49,23 @@ class Engine:
         if rc != 0:
             raise AmvsError(f"amvs_create failed ({rc}): {self._lib.amvs_last_error(None).decode()}")
         self._h = h
+        if mode != "exact":
+            self.set_mode(mode)
+
+    # -- arithmetic mode ------------------------------------------------------
+    def set_mode(self, mode):
+        """'exact' (bit-identical to the reference's float32 chain) or 'fast' (tolerance mode,
+        8-bit images only): applies to every later sweep call of this engine."""
+        self._chk(self._lib.amvs_set_mode(self._h, _lib.MODES[mode]))
+
+    def mode(self):
+        return {1: "exact", 2: "fast"}[int(self._lib.amvs_get_mode(self._h))]
+
+    def set_sampling(self, force_f32):
+        self._chk(self._lib.amvs_set_sampling(self._h, int(bool(force_f32))))
+
+    def set_sweep_tuning(self, tile_rows=0, planes_per_wave=0):
+        self._chk(self._lib.amvs_set_sweep_tuning(self._h, int(tile_rows), int(planes_per_wave)))
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
@@ -155,6 +173,18 @@ class Engine:
         out = np.empty((self.H, self.W), np.float32)
         self._chk(self._lib.amvs_eval_cost(self._h, int(ref), srcp, src.size, int(patch_size), _p(depth), _p(out)))
         return out
+
+    def sample_sources(self, ref, src_ids, patch_size, depth, bounds=0):
+        """(sampled (S,H,W) float32, valid (S,H,W) bool) of the stage before the box filter; in
+        fast mode the samples are in 8-bit code units (gray * 255)."""
+        src, srcp = _ids(src_ids)
+        depth = _f32(depth, (self.H, self.W))
+        out = np.empty((src.size, self.H, self.W), np.float32)
+        bits = np.empty((self.H, self.W), np.uint8)
+        self._chk(self._lib.amvs_sample_sources(self._h, int(ref), srcp, src.size, int(patch_size), int(bounds),
+                                                _p(depth), _p(out), bits.ctypes.data_as(C.POINTER(C.c_uint8))))
+        valid = np.stack([(bits >> s) & 1 for s in range(src.size)]).astype(bool)
+        return out, valid
 
     def confidence(self, ref, src_ids, patch_size, depth):
         src, srcp = _ids(src_ids)

@@ -63,16 +63,19 @@ def allgather_packed(local, n_items: int, width: int, group=None, device=None):
     return torch.cat(parts, dim=0)
 
 
-def allgather_maps(local_maps: dict, n_items: int, shape, group, map_type):
+def allgather_maps(local_maps: dict, n_items: int, shape, group, map_type, device_id=None):
     """Host-side convenience used by PatchMatchMVS._sweep: {item index -> map_type} of this
-    rank's shard in, all items out.  Packs depth|normal|confidence = 5 floats per pixel."""
+    rank's shard in, all items out.  Packs depth|normal|confidence = 5 floats per pixel.
+    device_id: the GPU the caller's engine runs on (RCCL gathers device tensors; defaults to
+    LOCAL_RANK only when the caller does not say)."""
     import torch
 
     H, W = shape
     rank, world = rank_world(group)
     mine = shard(n_items, rank, world)
     use_cuda = torch.distributed.get_backend(group) == "nccl"
-    dev = torch.device("cuda", local_device()) if use_cuda else torch.device("cpu")
+    dev = torch.device("cuda", local_device() if device_id is None else int(device_id)) if use_cuda \
+        else torch.device("cpu")
     rows = np.zeros((len(mine), 5 * H * W), np.float32)
     for n, j in enumerate(mine):
         m = local_maps[j]

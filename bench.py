@@ -10,16 +10,21 @@
 A "step" is one complete PatchMatch sweep (init, 8 x (2 propagation + 8 refinement) cost
 evaluations, confidence) over this rank's batch of reference views, with every image already
 resident in HBM.  Workload at N=1: BASELINE config 3 -- 16 views of 1920x1080, 7x7 NCC,
-4 sources, 8 iterations.  For N>1 every rank sweeps its own block of 16 views of a 16*N-view
-scene (weak scaling; all images replicated on every GPU because source sets cross shard
-boundaries) and the per-view maps (depth, normal, confidence: 20 B/pixel) are all-gathered
-over RCCL inside the timed step (in two batches per step, the exchange of the first overlapping the
-sweep of the second).
+4 sources, 8 iterations.  For N>1 the scene is FIXED (BASELINE config 4: 32 views of 1920x1080;
+north_star's scaling target is 8 GPUs vs 1 on a 32-view scene): rank r sweeps its contiguous block
+of ceil(32/N) views (all images replicated on every GPU because source sets cross shard boundaries)
+and the per-view maps (depth, normal, confidence: 20 B/pixel) are all-gathered over RCCL inside the
+timed step (in two batches per step, the exchange of the first overlapping the sweep of the
+second) -- "scaling": "strong".  `--scaling weak` restores 16 views per GPU of a 16*N-view scene.
+
+`--mode fast` (default) times the tolerance arithmetic (AMVS_MODE_FAST), `--mode exact` the
+bit-exact one; both are parity-tested at this very size and launch shape
+(tests/test_hip_fullsize_parity.py).
 
 Prints ONE JSON line (rank 0) with the throughput in Mpixel-hypotheses/s, the HBM-roofline
-figure of the dominant kernel (pm_step_kernel<7,4>, timed with HIP events on its own stream
-through amvs_get_timing) and -- at N=1 -- the CPU oracle timed on the host cores on a bounded
-sample of the same workload.
+figure of the dominant kernel (pm_step[_fast]_kernel<7,4>, timed with HIP events on its own stream
+through amvs_get_timing), -- at N=1 -- the CPU oracle (same arithmetic mode) timed on the host
+cores on a bounded sample of the same workload, and a `planesweep` sub-record (BASELINE config 2).
 """
 import argparse
 import json
@@ -52,11 +57,29 @@ def profiled_traffic(kernel_key, workload_key):
     return None
 
 
-def cpu_baseline(scene, patch, sources, refs, depth_min, depth_max, iters, samples):
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota if there is one (a GPU box exposes
+    every host core but grants a share), else the affinity mask, else os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or n
+
+
+def cpu_baseline(scene, patch, sources, refs, depth_min, depth_max, iters, samples, mode):
     """Time the CPU oracle (oracle/amvs_oracle.c, OpenMP over the host cores) on a bounded
     sample: the given reference views of the workload with the full iteration schedule."""
     from oracle import oracle
-    oracle.set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or 16)   # the box's CPU share
+    oracle.set_threads(host_cores())
     K = scene.camera.K.astype(np.float32)
     H, W = scene.grays[refs[0]].shape
     dt = 0.0
@@ -64,7 +87,7 @@ def cpu_baseline(scene, patch, sources, refs, depth_min, depth_max, iters, sampl
         srcs = sources[ref]
         ctx = oracle.ViewContext(K, scene.grays[ref], scene.poses[ref].R, scene.poses[ref].t,
                                  [scene.grays[i] for i in srcs], [scene.poses[i].R for i in srcs],
-                                 [scene.poses[i].t for i in srcs], patch)
+                                 [scene.poses[i].t for i in srcs], patch, mode=mode)
         t0 = time.time()
         ctx.patchmatch(0, 0, depth_min, depth_max, 1, ref)            # init + confidence only
         t_fixed = time.time() - t0
@@ -76,7 +99,8 @@ def cpu_baseline(scene, patch, sources, refs, depth_min, depth_max, iters, sampl
     return {"value": n_hyp / max(dt, 1e-9) / 1e6, "unit": "Mpx-hyp/s", "cores": oracle.num_threads(),
             "kind": "port",
             "sample": f"{len(refs)} of the views at {W}x{H}, {iters} iterations x (2+{samples}) evaluations = "
-                      f"{n_hyp/1e6:.1f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, OpenMP)"}
+                      f"{n_hyp/1e6:.1f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, {mode} arithmetic, "
+                      f"OpenMP on {oracle.num_threads()} threads)"}
 
 
 def main():
@@ -98,9 +122,16 @@ def main():
                          "0 = 1 on one GPU, 2 otherwise")
     ap.add_argument("--workload", choices=["patchmatch", "planesweep"], default="patchmatch")
     ap.add_argument("--planes", type=int, default=64)
+    ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
+                    help="arithmetic of the sweep kernels (include/amvs.h AMVS_MODE_*)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")
+    ap.add_argument("--scene-views", type=int, default=32, help="views of the fixed scene for N>1 (BASELINE config 4)")
+    ap.add_argument("--no-planesweep", action="store_true", help="skip the plane-sweep sub-record")
     args = ap.parse_args()
     if args.workload == "planesweep":
-        return main_planesweep(args)
+        print(json.dumps(run_planesweep(args, args.steps, args.warmup, not args.no_cpu_baseline)), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -129,8 +160,10 @@ def main():
     from amvs.parallel import shard
     from amvs.synthetic import make_scene
 
-    H, W, vpg = args.height, args.width, args.views_per_gpu
-    n_views = vpg * world
+    H, W = args.height, args.width
+    strong = world > 1 and args.scaling == "strong"
+    n_views = args.scene_views if strong else args.views_per_gpu * world
+    vpg = -(-n_views // world)                      # views per GPU (ceil)
     # synthetic calibrated scene rendered on the GPU (data generation, outside the timed region)
     sc = make_scene(n_views, H, W, seed=1234, device=str(dev))
     ids = sorted(sc.poses)
@@ -138,7 +171,7 @@ def main():
     sources = {r: pm._select_source_views(r, ids, sc.poses, k=4) for r in ids}
     mine = shard(n_views, rank, world)
 
-    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=local)
+    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=local, mode=args.mode)
     stream = torch.cuda.Stream(device=dev)
     eng.set_stream(stream.cuda_stream)
     # 8-bit images, as every real input is (cvtColor(...).astype(float32)/255,
@@ -248,6 +281,7 @@ def main():
     n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
     S = 4
+    kname = ("pm_step_fast_kernel" if args.mode == "fast" else "pm_step_kernel") + f"<{args.patch},{S}>"
     bytes_per_hyp = 4 * S + 44                       # 60 B at S=4
     launch_ms = sweep_ms / max(launches, 1)
     vpl = eng.last_views_per_launch()
@@ -264,23 +298,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: {vpg}-view {W}x{H} PatchMatch MVS per GPU, "
+            "config": {"workload": (f"BASELINE config 3: {n_views}-view {W}x{H} PatchMatch MVS, " if world == 1 else
+                                    f"BASELINE config 4: {n_views}-view {W}x{H} PatchMatch MVS scene, {vpg} views per GPU, "
+                                    f"RCCL all-gather of the maps, ") +
                                    f"{args.iters} iters x (2+{args.samples}) hypotheses, {args.patch}x{args.patch} NCC, "
-                                   f"{S} sources" + (f"; {n_views}-view scene, RCCL all-gather of maps" if world > 1 else ""),
-                       "views_per_gpu": vpg, "width": W, "height": H, "patch": args.patch,
-                       "iters": args.iters, "samples": args.samples, "sources": S,
+                                   f"{S} sources, {args.mode} arithmetic",
+                       "views_per_gpu": vpg, "scene_views": n_views, "width": W, "height": H, "patch": args.patch,
+                       "iters": args.iters, "samples": args.samples, "sources": S, "arithmetic": args.mode,
                        "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "views_per_launch": eng.last_views_per_launch(),
                        "batches_per_step": nb,
                        "pixel_hypotheses_per_step": n_hyp_step},
-            "roofline": {"bound": "hbm", "kernel": f"pm_step_kernel<{args.patch},{S}>",
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": profiled_traffic(f"pm_step_kernel<{args.patch},{S}>",
-                                                     f"{vpl}x{W}x{H}"),
+                         "traffic": profiled_traffic(kname, f"{vpl}x{W}x{H}"),
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
             "confidence_ms_per_step": round(conf_ms / args.steps, 3),
@@ -301,18 +336,25 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sample_refs = [n_views // 2, n_views // 2 + 1][: max(1, min(2, n_views))]
             out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources, sample_refs, sc.depth_min, sc.depth_max,
-                                               args.iters, args.samples)
+                                               args.iters, args.samples, args.mode)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
-        print(json.dumps(out), flush=True)
 
     eng.close()
+    del eng, depth, normal, conf
+    if rank == 0:
+        if world == 1 and not args.no_planesweep:
+            # BASELINE config 2 beside it: a few steps (about 10 ms each) and a short CPU leg
+            torch.cuda.empty_cache()
+            out["planesweep"] = run_planesweep(args, steps=5, warmup=1, with_cpu=not args.no_cpu_baseline, cpu_reps=3)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def main_planesweep(args):
+def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
     """BASELINE config 2: plane-sweep stereo (dense_stereo.py:222-316) over all views of a
-    1280x720 8-view scene, 64 inverse-depth planes, 5x5 NCC, 6 nearest neighbours."""
+    1280x720 8-view scene, 64 inverse-depth planes, 5x5 NCC, 6 nearest neighbours.  Returns the
+    record (same fields as the main line)."""
     import torch
 
     import amvs
@@ -330,7 +372,7 @@ def main_planesweep(args):
     ids = sorted(sc.poses)
     nbrs = {r: ds._find_neighbors(r, ids, sc.poses, k=S) for r in ids}
     depths = (1.0 / np.linspace(1 / sc.depth_max, 1 / sc.depth_min, D)).astype(np.float32)
-    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=0)
+    eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=0, mode=args.mode)
     stream = torch.cuda.Stream(device=dev)
     eng.set_stream(stream.cuda_stream)
     lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(dev)
@@ -340,6 +382,7 @@ def main_planesweep(args):
         sc.grays[i] = g.cpu().numpy()
         eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
         torch.cuda.synchronize()
+    kname = ("plane_sweep_fast_kernel" if args.mode == "fast" else "plane_sweep_kernel") + f"<{patch},{S}>"
     dmap = torch.empty((n_views, H, W), dtype=torch.float32, device=dev)
     conf = torch.empty((n_views, H, W), dtype=torch.float32, device=dev)
     refs = ids
@@ -349,40 +392,41 @@ def main_planesweep(args):
         eng.plane_sweep_device(refs, nb, depths, patch, 0.8, dmap.data_ptr(), conf.data_ptr())
         eng.sync()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         kernel_ms += eng.timing()["sweep_ms"]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     n_hyp = n_views * H * W * D
-    value = n_hyp * args.steps / elapsed / 1e6
+    value = n_hyp * steps / elapsed / 1e6
     bytes_per_hyp = 4 * S + 4 + 8.0 / D
-    launch_ms = kernel_ms / args.steps
+    launch_ms = kernel_ms / steps
     achieved = bytes_per_hyp * n_hyp / (launch_ms * 1e-3) / 1e9
     out = {"metric": "Mpixel-hypotheses/s (plane sweep)", "value": round(value, 1), "unit": "Mpx-hyp/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+           "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE config 2: {n_views}-view {W}x{H} plane-sweep stereo, {D} planes, "
-                                  f"{patch}x{patch} NCC, {S} neighbours", "sampling": eng.sampling_mode(),
+                                  f"{patch}x{patch} NCC, {S} neighbours, {args.mode} arithmetic",
+                      "arithmetic": args.mode, "sampling": eng.sampling_mode(),
                       "tile_rows": eng.last_tile_rows(), "pixel_hypotheses_per_step": n_hyp},
-           "roofline": {"bound": "hbm", "kernel": f"plane_sweep_kernel<{patch},{S}>", "achieved": round(achieved, 1),
+           "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": profiled_traffic(f"plane_sweep_kernel<{patch},{S}>", f"{n_views}x{W}x{H}"),
+                        "traffic": profiled_traffic(kname, f"{n_views}x{W}x{H}"),
                         "algorithmic_bytes_per_launch": int(bytes_per_hyp * n_hyp),
-                        "avg_launch_ms": round(launch_ms, 4), "launches_timed": args.steps}}
-    if not args.no_cpu_baseline:
-        oracle.set_threads(int(os.environ.get("AMVS_ORACLE_THREADS", "0")) or 16)
+                        "avg_launch_ms": round(launch_ms, 4), "launches_timed": steps}}
+    if with_cpu:
+        oracle.set_threads(host_cores())
         r = n_views // 2
         ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), sc.grays[r], sc.poses[r].R, sc.poses[r].t,
                                  [sc.grays[i] for i in nbrs[r]], [sc.poses[i].R for i in nbrs[r]],
-                                 [sc.poses[i].t for i in nbrs[r]], patch)
-        reps = 8
+                                 [sc.poses[i].t for i in nbrs[r]], patch, mode=args.mode)
+        reps = cpu_reps
         t0 = time.time()
         for _ in range(reps):
             ctx.plane_sweep(depths, 0.8)
@@ -390,9 +434,10 @@ def main_planesweep(args):
         out["cpu_baseline"] = {"value": round(reps * H * W * D / dt / 1e6, 2), "unit": "Mpx-hyp/s",
                                "cores": oracle.num_threads(), "kind": "port",
                                "sample": f"1 view at {W}x{H}, all {D} planes, {reps} repetitions = "
-                                         f"{reps*H*W*D/1e6:.0f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, OpenMP)"}
-    print(json.dumps(out), flush=True)
+                                         f"{reps*H*W*D/1e6:.0f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, "
+                                         f"{args.mode} arithmetic, OpenMP on {oracle.num_threads()} threads)"}
     eng.close()
+    return out
 
 
 if __name__ == "__main__":

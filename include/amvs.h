@@ -36,6 +36,22 @@ extern "C" {
 
 typedef struct amvs_ctx amvs_ctx;
 
+/* Arithmetic of the sweep kernels (SURVEY.md section 8b proposed a `mode` parameter).
+ *   AMVS_MODE_EXACT  every float32 operation of the reference's torch chain reproduced in order
+ *                    (mvs_patchmatch.py:341-411): bit-identical to the CPU oracle's exact mode,
+ *                    which matches torch-CPU bit for bit up to the box filter's summation order.
+ *   AMVS_MODE_FAST   the same algorithm with the projection precomposed per source, one
+ *                    reciprocal per projection and 8-bit code arithmetic:
+ *                    bit-identical to the CPU oracle's fast mode, which is pinned against the
+ *                    reference's golden vectors within the tolerances DESIGN.md states (cost
+ *                    mean 2e-6; >= 98 % of depths within 1e-3 relative end to end).  Needs 8-bit
+ *                    images (every view exactly code/255); otherwise the call fails with
+ *                    AMVS_EUNSUPPORTED.
+ * AMVS_MODE_DEFAULT in amvs_pm_params.mode means "the context's mode" (amvs_set_mode).          */
+#define AMVS_MODE_DEFAULT 0
+#define AMVS_MODE_EXACT   1
+#define AMVS_MODE_FAST    2
+
 /* PatchMatchMVS constructor parameters that reach the device path
  * (mvs_patchmatch.py:43-50) plus the depth range of _estimate_depth_range
  * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
@@ -48,6 +64,7 @@ typedef struct {
     int32_t views_per_launch; /* views swept together (cache residency); 0 = auto  */
     float   depth_min, depth_max;
     float   log_depth_scale, log_depth_min;
+    int32_t mode;             /* AMVS_MODE_DEFAULT / _EXACT / _FAST                    */
 } amvs_pm_params;
 
 /* Per-call device timing of the sweep kernels (HIP events on the context
@@ -92,9 +109,17 @@ int amvs_patchmatch_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const i
 int amvs_get_timing(const amvs_ctx *ctx, amvs_timing *out);
 /* 1 if the sweeps sample the packed 8-bit row-pair maps (every uploaded view is exactly
  * code/255, as cvtColor(...).astype(float32)/255 yields, mvs_patchmatch.py:177), 0 if they
- * sample the float32 maps.  Both give bit-identical results; AMVS_FORCE_F32_SAMPLING=1 in the
- * environment at amvs_create selects the float32 path unconditionally.                     */
+ * sample the float32 maps.  In exact mode both give bit-identical results;
+ * amvs_set_sampling(ctx, 1) selects the float32 path unconditionally (A/B tests).           */
 int amvs_sampling_mode(const amvs_ctx *ctx);
+int amvs_set_sampling(amvs_ctx *ctx, int force_f32);
+/* Arithmetic mode of every later sweep call of this context (PatchMatch with
+ * amvs_pm_params.mode == AMVS_MODE_DEFAULT, plane sweep, the single-step entry points).
+ * A new context is in AMVS_MODE_EXACT.                                                       */
+int amvs_set_mode(amvs_ctx *ctx, int mode);
+int amvs_get_mode(const amvs_ctx *ctx);
+/* Plane-sweep launch shape: rows per wave strip (1..32) and planes per wave; 0 = automatic.   */
+int amvs_set_sweep_tuning(amvs_ctx *ctx, int tile_rows, int planes_per_wave);
 /* Rows per wave strip the last sweep used (amvs_pm_params.tile_rows, or the automatic choice). */
 int amvs_last_tile_rows(const amvs_ctx *ctx);
 /* Views per launch group the last PatchMatch call used (amvs_pm_params.views_per_launch or auto). */
@@ -137,6 +162,13 @@ int amvs_fetch_cloud(amvs_ctx *ctx, double *points_out, uint8_t *colors_out);
 /* _compute_patch_cost (mvs_patchmatch.py:323-390): depth map in, averaged cost out. */
 int amvs_eval_cost(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
                    const float *depth_in, float *cost_out);
+/* The stage before the box filter (mvs_patchmatch.py:341-377): every pixel projected into every
+ * source at its own depth and sampled bilinearly.  sampled_out is [n_src][H][W] -- gray in exact
+ * mode, 8-bit code units (gray * 255) in fast mode --, valid_out [H][W] holds bit s = source s
+ * valid.  bounds: 0 = patch bounds (:362-363), 1 = image bounds (:516-517), 2 = depth test only
+ * (dense_stereo.py:280,303).                                                                    */
+int amvs_sample_sources(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size, int bounds,
+                        const float *depth_in, float *sampled_out, uint8_t *valid_out);
 /* _compute_confidence (mvs_patchmatch.py:493-534). */
 int amvs_confidence(amvs_ctx *ctx, int ref, const int *src_ids, int n_src, int patch_size,
                     const float *depth_in, float *conf_out);

@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_backend(scene, patch, iters, samples, seed):
+def _oracle_backend(scene, patch, iters, samples, seed, mode="exact"):
     """Sweep backend on the CPU oracle, fed with the same prepared gray maps the engine gets
     (BGR -> gray of the colour images, as reconstruct() does)."""
     from oracle import oracle
@@ -29,21 +29,22 @@ def _oracle_backend(scene, patch, iters, samples, seed):
         for ref, srcs in jobs:
             ctx = oracle.ViewContext(scene.K32(), grays[ref], scene.R[ref], scene.t[ref],
                                      [grays[i] for i in srcs], [scene.R[i] for i in srcs],
-                                     [scene.t[i] for i in srcs], patch)
+                                     [scene.t[i] for i in srcs], patch, mode=mode)
             a, b, e = ctx.patchmatch(iters, samples, scene.depth_min, scene.depth_max, seed, ref)
             d.append(a); n.append(b); c.append(e)
         return np.stack(d), np.stack(n), np.stack(c)
     return run
 
 
-def _reconstruct(scene, world_tag, use_engine=False):
-    """PatchMatchMVS.reconstruct; without a GPU the device sweep is replaced by the oracle backend."""
+def _reconstruct(scene, world_tag, use_engine=False, mode="exact"):
+    """PatchMatchMVS.reconstruct; without a GPU the device sweep is replaced by the oracle backend
+    (in the same arithmetic mode)."""
     import amvs
     from amvs.core.mvs_patchmatch import PatchMatchMVS
     pm = PatchMatchMVS(amvs.Camera(K=scene.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7,
-                       num_iterations=1, num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0)
+                       num_iterations=1, num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0, mode=mode)
     if not use_engine:
-        backend = _oracle_backend(scene, 7, 1, 2, 5)
+        backend = _oracle_backend(scene, 7, 1, 2, 5, mode)
         pm._ensure_engine = lambda images, poses, indices: setattr(pm, "_slot", {i: i for i in indices})
         pm._run_batch = lambda eng, batch: backend(batch)
         pm.device_fusion = False        # host maps + NumPy fusion (bit-identical to the device path)
@@ -53,7 +54,7 @@ def _reconstruct(scene, world_tag, use_engine=False):
     return pm.reconstruct([{"image": c} for c in scene.colors], scene.poses())
 
 
-def _worker(rank, world, port, q, use_engine=False):
+def _worker(rank, world, port, q, use_engine=False, mode="exact", backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       AMVS_ORACLE_THREADS="2")
     sys.path.insert(0, ROOT)
@@ -62,16 +63,24 @@ def _worker(rank, world, port, q, use_engine=False):
     import torch.distributed as dist
     from conftest import GoldenScene
     from amvs import parallel
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        # one rank per GPU over RCCL: bind the device before anything touches it
+        os.environ["LOCAL_RANK"] = str(rank)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # 1. raw collective: uneven shards (5 items over 2 ranks -> 3 + 2)
         mine = parallel.shard(5, rank, world)
         local = torch.tensor([[float(j), j * 10.0, j + 0.5] for j in mine], dtype=torch.float32).reshape(len(mine), 3)
-        full = parallel.allgather_packed(local, 5, 3)
+        if backend == "nccl":
+            local = local.cuda()
+        full = parallel.allgather_packed(local, 5, 3).cpu()
         want = torch.tensor([[float(j), j * 10.0, j + 0.5] for j in range(5)], dtype=torch.float32)
         assert torch.equal(full, want), (rank, full)
         # 2. the sharded reconstruct path
-        pts, cols = _reconstruct(GoldenScene("scene_a"), f"rank{rank}", use_engine)
+        pts, cols = _reconstruct(GoldenScene("scene_a"), f"rank{rank}", use_engine, mode)
         q.put((rank, pts, cols))
     finally:
         dist.destroy_process_group()
@@ -96,12 +105,12 @@ def test_two_rank_gloo_matches_single_process(scene_a):
         assert np.array_equal(cols, single_cols)
 
 
-def _run_two_ranks(use_engine):
+def _run_two_ranks(use_engine, mode="exact", backend="gloo"):
     import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
+    ctx = mp.get_context("spawn")                    # fresh processes: nothing has touched a GPU yet
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_engine)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, use_engine, mode, backend)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
@@ -113,14 +122,84 @@ def _run_two_ranks(use_engine):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_reconstruct_on_gpu_single_and_two_ranks(scene_a):
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_reconstruct_on_gpu_single_and_two_ranks(scene_a, mode):
     """The drop-in class end to end on the HIP engine: (1) its fused cloud equals the one obtained
-    with the CPU oracle as sweep backend (the sweep is bit-exact, the host geometry is shared);
-    (2) two ranks (gloo, both on cuda:0) sharding the views return the same cloud on every rank."""
-    gpu_pts, gpu_cols = _reconstruct(scene_a, "gpu", use_engine=True)
-    cpu_pts, cpu_cols = _reconstruct(scene_a, "oracle", use_engine=False)
+    with the CPU oracle (same arithmetic mode) as sweep backend (the sweep is bit-exact, the host
+    geometry is shared); (2) two ranks (gloo, both on cuda:0) sharding the views return the same
+    cloud on every rank."""
+    gpu_pts, gpu_cols = _reconstruct(scene_a, "gpu", use_engine=True, mode=mode)
+    cpu_pts, cpu_cols = _reconstruct(scene_a, "oracle", use_engine=False, mode=mode)
     assert gpu_pts.shape[0] > 0
     assert np.array_equal(gpu_pts, cpu_pts) and np.array_equal(gpu_cols, cpu_cols)
-    for rank, pts, cols in _run_two_ranks(True):
+    for rank, pts, cols in _run_two_ranks(True, mode):
         assert np.array_equal(pts, gpu_pts), f"rank {rank}"
         assert np.array_equal(cols, gpu_cols)
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()          # does not initialise the GPU on this image
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(_gpu_count() < 2, reason="the RCCL path needs two GPUs (one rank per GPU)")
+def test_reconstruct_two_ranks_rccl_matches_single_process(scene_a):
+    """One rank per GPU, backend nccl (= RCCL over xGMI): the device-resident all-gather of
+    _sweep_resident and the fused cloud must equal the single-process result.  Skipped on the
+    one-GPU test boxes; runs wherever two devices are visible.  Workers are fresh spawned processes
+    that bind their device before any other GPU call."""
+    single_pts, single_cols = _reconstruct(scene_a, "single", use_engine=True, mode="fast")
+    for rank, pts, cols in _run_two_ranks(True, "fast", backend="nccl"):
+        assert np.array_equal(pts, single_pts), f"rank {rank} cloud differs from the single-process cloud"
+        assert np.array_equal(cols, single_cols)
+
+
+def test_engine_cache_follows_the_poses(monkeypatch, scene_a):
+    """ADVICE (round 1): the engine cache must not serve stale poses.  _patchmatch_cuda takes the
+    poses on every call, as the reference does (mvs_patchmatch.py:225-257): changed poses, a
+    different prepared dict or a different image size re-upload; identical inputs reuse the engine."""
+    import amvs
+    from amvs import engine as engine_mod
+    from amvs.core.mvs_patchmatch import PatchMatchMVS
+
+    uploads = []
+
+    class FakeEngine:
+        def __init__(self, H, W, n, K, device=0, mode="exact"):
+            self.H, self.W = H, W
+
+        def set_view(self, slot, gray, R, t):
+            uploads.append((slot, np.asarray(t, np.float64).copy()))
+
+        def patchmatch(self, refs, srcs, params, seed):
+            n = len(refs)
+            return (np.zeros((n, self.H, self.W), np.float32), np.zeros((n, self.H, self.W, 3), np.float32),
+                    np.zeros((n, self.H, self.W), np.float32))
+
+        def timing(self):
+            return {}
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(engine_mod, "Engine", FakeEngine)
+    pm = PatchMatchMVS(amvs.Camera(K=scene_a.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7, device=0)
+    images = {i: {"gray": scene_a.grays[i], "color": scene_a.colors[i], "shape": scene_a.grays[i].shape}
+              for i in range(scene_a.n)}
+    poses = scene_a.poses()
+    pm._patchmatch_cuda(2, [1, 3], images, poses)
+    assert len(uploads) == scene_a.n
+    pm._patchmatch_cuda(2, [1, 3], images, poses)
+    assert len(uploads) == scene_a.n                               # same dict, same poses: reused
+    moved = dict(poses)
+    moved[1] = amvs.CameraPose(R=poses[1].R.copy(), t=poses[1].t + np.array([0.01, 0.0, 0.0]))
+    pm._patchmatch_cuda(2, [1, 3], images, moved)
+    assert len(uploads) == 2 * scene_a.n                           # refined pose: everything re-uploaded
+    assert np.allclose(uploads[-scene_a.n + 1][1], moved[1].t)
+    pm._patchmatch_cuda(2, [1, 3], dict(images), moved)            # an equal but different dict object
+    assert len(uploads) == 3 * scene_a.n
