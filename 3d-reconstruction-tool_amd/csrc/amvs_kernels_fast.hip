@@ -33,6 +33,11 @@ namespace amvs {
 #ifndef AMVS_FAST_MIN_WAVES_BIAS
 #define AMVS_FAST_MIN_WAVES_BIAS 0
 #endif
+// extra dynamic LDS per workgroup of the sweep step: caps the resident workgroups per CU
+// (160 KiB / (static + extra)); fewer resident waves touch fewer source rows at once
+#ifndef AMVS_FAST_STEP_EXTRA_LDS
+#define AMVS_FAST_STEP_EXTRA_LDS 0
+#endif
 
 template <int S> struct FRing {
     static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void sample_dump_fast_kernel(const StepA
 {
     const JobCP job = (JobCP)a.jobs;
     const int H = a.H, W = a.W;
-    const FastConsts fc = make_fast_consts(H, W, a.mode == MODE_CONF ? 0 : a.TH);   // TH carries k/2 here
+    const FastConsts fc = make_fast_consts(H, W, a.mode == MODE_EVAL ? a.TH : 0);   // TH carries k/2 here
     const long long HW = (long long)H * W;
     const int x = blockIdx.x * AMVS_WAVE + threadIdx.x, y = blockIdx.y;
     const bool live = x < W;
@@ -700,9 +705,10 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
-    if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, 0, st, a);
-    else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, 0, st, a);
+    constexpr unsigned XL = AMVS_FAST_STEP_EXTRA_LDS;
+    if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, XL, st, a);
+    else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, XL, st, a);
+    else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, XL, st, a);
     return hipGetLastError();
 }
 
@@ -718,7 +724,8 @@ static int step_fast_occupancy_ks()
 {
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB,
+                                                                AMVS_FAST_STEP_EXTRA_LDS);
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
