@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
 MODES = {"default": 0, "exact": 1, "fast": 2}
+SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2}
 SUPPORTED_PATCH_SIZES = (3, 5, 7, 9, 11)
 
 f32p = C.POINTER(C.c_float)
@@ -22,7 +23,8 @@ class PmParams(C.Structure):
     _fields_ = [("patch_size", C.c_int32), ("num_iterations", C.c_int32),
                 ("num_samples", C.c_int32), ("tile_rows", C.c_int32), ("views_per_launch", C.c_int32),
                 ("depth_min", C.c_float), ("depth_max", C.c_float),
-                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float), ("mode", C.c_int32)]
+                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float), ("mode", C.c_int32),
+                ("schedule", C.c_int32)]
 
 
 class Timing(C.Structure):

@@ -49,6 +49,7 @@ struct amvs_ctx {
     std::vector<char> exact8;
     bool force_f32 = false;             // amvs_set_sampling: A/B switch for tests
     int mode = AMVS_MODE_EXACT;         // arithmetic of the sweeps (amvs_set_mode)
+    int default_band_major = 0;         // schedule of amvs_pm_params.schedule == 0 (view-major measured faster)
     int sweep_tile_rows = 0, sweep_chunk = 0;   // amvs_set_sweep_tuning (0 = automatic)
     std::map<int, Stats> stats;
     std::map<int, FastStats> fstats;    // fast mode: (mean1, var1) maps per patch size
@@ -285,6 +286,25 @@ int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requ
         if (waves >= 3 * slots) return th;
     }
     return 8;
+}
+
+// Band-major schedule (StepArgs::band_major): strip height such that ONE band of all views of the
+// launch about fills an XCD's wave slots, i.e. every XCD walks its own band(s) of all views top to
+// bottom in one generation of waves.  Few views: several adjacent bands per XCD.
+int pick_band_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, bool fast)
+{
+    const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
+    const long long slots_xcd = (long long)(c->n_cu / 8 > 0 ? c->n_cu / 8 : 1) *
+                                (fast ? amvs::step_fast_waves_per_cu(patch, n_src)
+                                      : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr));
+    const long long per_band = (long long)n_jobs * tiles_x;
+    long long g = slots_xcd / per_band;             // bands resident together per XCD
+    if (g < 1) g = 1;
+    const long long bands = 8 * g;
+    long long th = (c->H + bands - 1) / bands;
+    const int min_th = 2 * patch > 8 ? 2 * patch : 8;
+    if (th < min_th) th = min_th;
+    return (int)th;
 }
 
 amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
@@ -550,7 +570,11 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     // `vpl` views, each group through the whole schedule (see default_views_per_launch).
     int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
     if (vpl > n_ref) vpl = n_ref;
-    const int TH = pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0);
+    if (p->schedule < 0 || p->schedule > 2) return fail(c, AMVS_EINVAL, "unknown schedule");
+    const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
+    const int TH = p->tile_rows > 0 || !band_major
+                       ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0)
+                       : pick_band_rows(c, p->patch_size, n_src, vpl, fast != 0);
     c->last_tile_rows = TH;
     resolve_timing(c);
     c->timing = amvs_timing{};
@@ -570,6 +594,7 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
         const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
         amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
         a.fast = fast;
+        a.band_major = band_major;
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;

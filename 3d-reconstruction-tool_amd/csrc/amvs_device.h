@@ -396,6 +396,9 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
 // would have to emit FLAT loads (which also count on the LDS/scalar wait counter)
 typedef const __attribute__((address_space(1))) char *GlobalBytes;
 typedef const __attribute__((address_space(1))) float *GlobalFloats;
+typedef const __attribute__((address_space(1))) uint16_t *GlobalU16;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x2_t *GlobalFloat2s;
 
 // The four codes of a footprint whose origin is texel index `off` (non-negative) of the padded map
 // starting at `img`: uniform 64-bit base + 32-bit byte offset, i.e. the scalar-base form of

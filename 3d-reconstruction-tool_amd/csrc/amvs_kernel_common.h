@@ -33,6 +33,24 @@ AMVS_DEV int xcd_remap(int bid, int nblk)
     return base + (bid >> 3);
 }
 
+// strip index -> (job, strip row, strip column); see StepArgs::band_major
+AMVS_DEV void strip_of(const StepArgs &a, int t, int &job_id, int &ty, int &tx)
+{
+    if (a.band_major) {
+        const int per_band = a.n_jobs * a.tiles_x;
+        ty = t / per_band;
+        const int rem = t - ty * per_band;
+        job_id = rem / a.tiles_x;
+        tx = rem - job_id * a.tiles_x;
+    } else {
+        const int tiles_per_job = a.tiles_x * a.tiles_y;
+        job_id = t / tiles_per_job;
+        const int rem = t - job_id * tiles_per_job;
+        ty = rem / a.tiles_x;
+        tx = rem - ty * a.tiles_x;
+    }
+}
+
 // per-row validity bits of the last K/2+1 rows packed into one (or two) registers
 template <int K, int S> struct Hist {
     typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;

@@ -54,6 +54,12 @@ struct StepArgsBase {
 
 struct StepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs;
+    // Strip order.  0 (view-major): strips run view by view, row by row -- an XCD's resident
+    // waves cover ~19 consecutive strip rows of one view.  1 (band-major): strips run band by band
+    // (a band = one strip row of EVERY view of the launch), so an XCD's resident waves walk the same
+    // rows of all views together; the views' source images are each other, so the XCD's L2 holds
+    // one thin row front of every image instead of a tall band of a few.
+    int band_major;
     // State [slot][H*W] (normals [slot][H*W*3]).  Depth is ping-ponged on every step (halo pixels
     // of other strips read the pre-step map).  Cost and normals are only ever touched at a lane's
     // own pixel: cost is updated in place; normals are updated in place by refinement steps (only

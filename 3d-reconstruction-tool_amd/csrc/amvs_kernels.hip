@@ -300,10 +300,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
     if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
-    const int job_id = t / tiles_per_job;
-    const int rem = t - job_id * tiles_per_job;
-    const int ty = rem / a.tiles_x;
-    const int tx = rem - ty * a.tiles_x;
+    int job_id, ty, tx;
+    strip_of(a, t, job_id, ty, tx);
 
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
@@ -311,10 +309,10 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 
     const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
     // ref gray of the packed path: low byte of the padded row-pair map (pitch W+4, origin at pixel (0,0))
-    const uint16_t *__restrict__ ref_pairs = U8 ? (const uint16_t *)job->ref_pairs : a.pairs;
+    const GlobalU16 ref_pairs = U8 ? (GlobalU16)job->ref_pairs : (GlobalU16)a.pairs;   // global, not FLAT, loads
     constexpr int PADW = U8 ? 2 * AMVS_PAIR_BORDER : 0;
 #if AMVS_CODE_BYTES
-#define AMVS_REF_CODE(i) (((const uint8_t *)ref_pairs)[i])
+#define AMVS_REF_CODE(i) (((const __attribute__((address_space(1))) uint8_t *)ref_pairs)[i])
 #else
 #define AMVS_REF_CODE(i) (ref_pairs[i])
 #endif
@@ -925,12 +923,32 @@ hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st)
 }
 
 // ------------------------------------------------------------------ dispatch -----
+// Resident workgroups per CU of the sweep step are capped through unused dynamic LDS: the launch is
+// bound by the CU's L1 line rate for scattered gathers, not by latency, so waves beyond ~16 per CU
+// only widen the band of source rows an XCD touches at once (more L2 misses); measured on the fast
+// kernel 24 waves 0.897 ms, 20: 0.822, 16: 0.814, 12: 0.856 (amvs_kernels_fast.hip).
+#ifndef AMVS_MAX_WGS_PER_CU
+#define AMVS_MAX_WGS_PER_CU 4
+#endif
+template <auto Kern>
+static unsigned step_extra_lds()
+{
+    static const unsigned extra = [] {
+        hipFuncAttributes at{};
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(Kern)) != hipSuccess) return 0u;
+        const unsigned share = 160u * 1024u / AMVS_MAX_WGS_PER_CU;
+        return (unsigned)at.sharedSizeBytes < share ? share - (unsigned)at.sharedSizeBytes : 0u;
+    }();
+    return extra;
+}
+
 template <int K, int S>
 static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
-#define AMVS_LAUNCH_STEP(U8, M) hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, 0, st, a)
+#define AMVS_LAUNCH_STEP(U8, M) \
+    hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, (step_extra_lds<&pm_step_kernel<K, S, U8, M>>()), st, a)
     if (a.pairs) {
         if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(true, MODE_REFINE);
         else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(true, MODE_PROP);
@@ -969,8 +987,10 @@ static int step_occupancy_ks(bool u8)
 {
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
-    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true, MODE_REFINE>, TPB, 0)
-                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false, MODE_REFINE>, TPB, 0);
+    hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true, MODE_REFINE>, TPB,
+                                                                     step_extra_lds<&pm_step_kernel<K, S, true, MODE_REFINE>>())
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false, MODE_REFINE>, TPB,
+                                                                     step_extra_lds<&pm_step_kernel<K, S, false, MODE_REFINE>>());
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 

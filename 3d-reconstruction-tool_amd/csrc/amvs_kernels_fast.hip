@@ -33,15 +33,24 @@ namespace amvs {
 #ifndef AMVS_FAST_MIN_WAVES_BIAS
 #define AMVS_FAST_MIN_WAVES_BIAS 0
 #endif
-// extra dynamic LDS per workgroup of the sweep step: caps the resident workgroups per CU
-// (160 KiB / (static + extra)); fewer resident waves touch fewer source rows at once
-#ifndef AMVS_FAST_STEP_EXTRA_LDS
-#define AMVS_FAST_STEP_EXTRA_LDS 0
+// Resident workgroups per CU of the sweep step, enforced through unused dynamic LDS (160 KiB /
+// (static + extra)).  Fewer resident waves touch fewer source rows at once: measured on MI355X
+// (16 views 1080p, k=7, S=4, ms per launch) 6 workgroups = 24 waves per CU 0.897, 5: 0.822, 4: 0.814,
+// 3: 0.856 -- the launch is bound by the CU's L1 line rate for scattered gathers (2 cycles per distinct
+// 128-byte line, tools/gather_rate.hip), not by latency, so the extra waves only add L2 misses.
+#ifndef AMVS_FAST_MAX_WGS_PER_CU
+#define AMVS_FAST_MAX_WGS_PER_CU 4
 #endif
 
 template <int S> struct FRing {
     static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
     static constexpr int NR = S - NL > 0 ? S - NL : 1;
+};
+
+template <int K, int S> struct StepLds {
+    static constexpr unsigned STATIC = AMVS_WG_WAVES * ((FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u);
+    static constexpr unsigned SHARE = 160u * 1024u / AMVS_FAST_MAX_WGS_PER_CU;
+    static constexpr unsigned EXTRA = STATIC < SHARE ? SHARE - STATIC : 0u;
 };
 
 // the last K reference codes of a lane's column as packed bytes: the window occupies the TOP K
@@ -255,7 +264,7 @@ AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr)
 
 constexpr int fast_min_waves(int K, int S)
 {
-    return ((S + 1) * K <= 40 ? 5 : ((S + 1) * K <= 60 ? 4 : 3)) + AMVS_FAST_MIN_WAVES_BIAS;
+    return ((S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_FAST_MIN_WAVES_BIAS;
 }
 
 // ------------------------------------------------------------------ sweep step ---
@@ -279,17 +288,17 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
     if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
-    const int job_id = t / tiles_per_job;
-    const int rem = t - job_id * tiles_per_job;
-    const int ty = rem / a.tiles_x;
-    const int tx = rem - ty * a.tiles_x;
+    int job_id, ty, tx;
+    strip_of(a, t, job_id, ty, tx);
 
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
     const long long HW = (long long)H * W;
     constexpr int PADW = 2 * AMVS_PAIR_BORDER;
-    const uint16_t *__restrict__ ref_pairs = (const uint16_t *)job->ref_pairs;
-    const float2 *__restrict__ ref_stats = (const float2 *)job->ref_stats;
+    // (global address space: a generic pointer would make these FLAT loads, which force vmcnt(0) and
+    // lgkmcnt(0) waits)
+    const GlobalU16 ref_pairs = (GlobalU16)job->ref_pairs;
+    const GlobalFloat2s ref_stats = (GlobalFloat2s)job->ref_stats;
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
     const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = outl ? yc * W + xc : 0;
         const float oldd = d_in[pc], oldc = cost_io[pc];
-        const float2 mv1 = ref_stats[pc];
+        const f32x2_t mv1 = ref_stats[pc];
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
 
@@ -486,8 +495,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const int H = a.H, W = a.W;
     const long long HW = (long long)H * W;
     constexpr int PADW = 2 * AMVS_PAIR_BORDER;
-    const uint16_t *__restrict__ ref_pairs = (const uint16_t *)job->ref_pairs;
-    const float2 *__restrict__ ref_stats = (const float2 *)job->ref_stats;
+    // (global address space: a generic pointer would make these FLAT loads, which force vmcnt(0) and
+    // lgkmcnt(0) waits)
+    const GlobalU16 ref_pairs = (GlobalU16)job->ref_pairs;
+    const GlobalFloat2s ref_stats = (GlobalFloat2s)job->ref_stats;
     const FastConsts fc = make_fast_consts(H, W, 0);
 
     const int xbase = tx * OUTW - HALF;
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             const int yc = yr - HALF;
             const int xc = xr + HALF;
             const bool outl = (lane < OUTW) & (xc < W);
-            const float2 mv1 = ref_stats[outl ? yc * W + xc : 0];
+            const f32x2_t mv1 = ref_stats[outl ? yc * W + xc : 0];
             const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
             float rr[K];
 #pragma unroll
@@ -705,7 +716,7 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
-    constexpr unsigned XL = AMVS_FAST_STEP_EXTRA_LDS;
+    constexpr unsigned XL = StepLds<K, S>::EXTRA;
     if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, XL, st, a);
     else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, XL, st, a);
     else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, XL, st, a);
@@ -725,7 +736,7 @@ static int step_fast_occupancy_ks()
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB,
-                                                                AMVS_FAST_STEP_EXTRA_LDS);
+                                                                StepLds<K, S>::EXTRA);
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 

@@ -24,14 +24,15 @@ def _ids(a):
 
 
 def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0,
-                   views_per_launch=0, mode="default"):
+                   views_per_launch=0, mode="default", schedule="auto"):
     """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does.
     mode: "default" (the engine's), "exact" or "fast" (include/amvs.h AMVS_MODE_*)."""
     log_min = np.log(float(depth_min))
     log_max = np.log(float(depth_max))
     return PmParams(int(patch_size), int(num_iterations), int(num_samples), int(tile_rows),
                     int(views_per_launch), float(depth_min), float(depth_max),
-                    float(np.float32(log_max - log_min)), float(np.float32(log_min)), _lib.MODES[mode])
+                    float(np.float32(log_max - log_min)), float(np.float32(log_min)), _lib.MODES[mode],
+                    _lib.SCHEDULES[schedule])
 
 
 class Engine:

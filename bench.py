@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
                     help="arithmetic of the sweep kernels (include/amvs.h AMVS_MODE_*)")
+    ap.add_argument("--schedule", choices=["auto", "view-major", "band-major"], default="auto",
+                    help="strip order of the sweep launches (amvs_pm_params.schedule)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")
     ap.add_argument("--scene-views", type=int, default=32, help="views of the fixed scene for N>1 (BASELINE config 4)")
@@ -184,7 +186,7 @@ def main():
         eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
         torch.cuda.synchronize()
     params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
-                            args.views_per_launch)
+                            args.views_per_launch, schedule=args.schedule)
     n_loc = len(mine)
     depth = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
     normal = torch.empty((n_loc, H, W, 3), dtype=torch.float32, device=dev)
@@ -310,7 +312,7 @@ def main():
                        "views_per_gpu": vpg, "scene_views": n_views, "width": W, "height": H, "patch": args.patch,
                        "iters": args.iters, "samples": args.samples, "sources": S, "arithmetic": args.mode,
                        "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "views_per_launch": eng.last_views_per_launch(),
-                       "batches_per_step": nb,
+                       "schedule": args.schedule, "batches_per_step": nb,
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

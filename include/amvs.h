@@ -65,6 +65,8 @@ typedef struct {
     float   depth_min, depth_max;
     float   log_depth_scale, log_depth_min;
     int32_t mode;             /* AMVS_MODE_DEFAULT / _EXACT / _FAST                    */
+    int32_t schedule;         /* strip order: 0 = automatic, 1 = view-major, 2 = band-major
+                                 (performance only; results do not depend on it)       */
 } amvs_pm_params;
 
 /* Per-call device timing of the sweep kernels (HIP events on the context
