@@ -41,17 +41,18 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def profiled_traffic(kernel_key, workload_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, written by tools/profile_summary.py; FETCH_SIZE + WRITE_SIZE in KiB,
-    collected in separate passes, uncorrected -- MI355X_MICROARCH.md notes FETCH_SIZE can
-    under-count wide streaming reads by 2x, dword gathers are uncalibrated).  None if no profile
-    of this exact workload is committed."""
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE in KiB,
+    collected in separate passes).  FETCH_SIZE is corrected as MI355X_MICROARCH.md prescribes: it
+    tallies every 128-byte L2 fill at 64 bytes, so it is doubled -- calibrated for THIS access pattern
+    with tools/gather_rate.hip (one dword per 128 bytes moves as many bytes as one per 64 bytes, and
+    TCC_MISS_sum x 64 B reproduces FETCH_SIZE).  None if no profile of this exact workload is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(kernel_key)
         if e and e.get("workload") == workload_key:
-            return int((e["fetch_kib"] + e["write_kib"]) * 1024)
+            return int((e["fetch_kib"] * e.get("fetch_correction", 1.0) + e["write_kib"]) * 1024)
     except (OSError, ValueError, KeyError):
         pass
     return None

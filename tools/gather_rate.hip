@@ -50,6 +50,39 @@ __global__ __launch_bounds__(64) void k(const char *__restrict__ tab, uint32_t m
     out[wave * 64 + lane] = o;
 }
 
+// Calibration of FETCH_SIZE for sparse reads: one dword per STRIDE bytes, lanes on consecutive
+// strides (so the request rate is not the limit).  If stride 128 takes as long as stride 64 over the
+// same buffer, an L2 miss moves the whole 128-byte line; if it takes half as long, only a 64-byte
+// sector.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void sweep(const char *__restrict__ tab, size_t bytes, uint32_t *out)
+{
+    const size_t n = bytes / STRIDE;
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v;
+        __builtin_memcpy(&v, tab + i * STRIDE, 4);
+        acc ^= v;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int STRIDE>
+void run_sweep(const char *tab, size_t bytes, uint32_t *out)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((sweep<STRIDE>), dim3(256 * 8), dim3(256), 0, 0, tab, bytes, out);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((sweep<STRIDE>), dim3(256 * 8), dim3(256), 0, 0, tab, bytes, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("sweep: one dword per %3d bytes over %.1f GB: %.3f ms  (%.2f TB/s if whole 128-B lines move, %.2f TB/s if 64-B sectors)\n",
+           STRIDE, bytes / 1e9, ms, bytes / (ms * 1e-3) / 1e12, (STRIDE >= 128 ? bytes / 2 : bytes) / (ms * 1e-3) / 1e12);
+}
+
 static char *g_tab;
 static uint32_t *g_out;
 
@@ -80,7 +113,11 @@ int main()
     const size_t big = 2048ull << 20;
     hipMalloc(&g_tab, big);
     hipMemset(g_tab, 1, big);
-    hipMalloc(&g_out, 256 * 32 * 64 * 4);
+    hipMalloc(&g_out, 256 * 32 * 64 * 4 * 4);
+    run_sweep<4>(g_tab, big, g_out);
+    run_sweep<64>(g_tab, big, g_out);
+    run_sweep<128>(g_tab, big, g_out);
+    run_sweep<256>(g_tab, big, g_out);
     for (size_t tb : {(size_t)2 << 20, (size_t)64 << 20, big}) {
         run<uint32_t, 1, 0>("dword, 64 random places", tb, 16);
         run<uint32_t, 2, 0>("dword, 32 places x 2 lanes", tb, 16);
