@@ -42,6 +42,8 @@ SIGNATURES = {
     "amvs_sync": (C.c_int, [C.c_void_p]),
     "amvs_set_view": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p, f32p]),
     "amvs_set_view_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, f32p, f32p]),
+    "amvs_set_view_bgr8": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, f32p, f32p,
+                                     C.POINTER(C.c_uint8)]),
     "amvs_patchmatch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(PmParams),
                                   C.c_uint64, f32p, f32p, f32p]),
     "amvs_patchmatch_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int,
@@ -59,6 +61,14 @@ SIGNATURES = {
                                    C.c_float, f32p, f32p]),
     "amvs_plane_sweep_device": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int,
                                           C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "amvs_plane_sweep_batch": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, f32p, C.c_int, C.c_int, C.c_float]),
+    "amvs_fetch_sweep_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, f32p, f32p]),
+    "amvs_stereo_backproject": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint8),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_float,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "amvs_cloud_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "amvs_cloud_voxel_downsample": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_double, C.POINTER(C.c_int64)]),
+    "amvs_knn_supported": (C.c_int, [C.c_int]),
     "amvs_eval_cost": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
     "amvs_sample_sources": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f32p, f32p,
                                       C.POINTER(C.c_uint8)]),

@@ -1,11 +1,27 @@
 """Image preparation in front of the sweep (reference mvs_patchmatch.py:167-191,
 dense_stereo.py:156-176): resize by `scale`, BGR -> gray, /255.
 
-The reference does this with OpenCV (cv.resize INTER_LINEAR, cv.cvtColor BGR2GRAY).
-When cv2 is importable it is used, so results are identical to the reference's;
-otherwise a NumPy restatement of OpenCV's documented formulas runs (parity with cv2
-unpinned: OpenCV is absent from the build container).  At scale 1.0 the resize is the
-identity in both.
+The reference does this with OpenCV (cv.resize INTER_LINEAR, cv.cvtColor BGR2GRAY; requirements.txt
+pins opencv-python>=4.5.0, which is NOT vendored and absent from the build container).  When cv2 is
+importable it is used, so results are the reference's by construction; otherwise the NumPy
+restatement below runs -- the published algorithm of OpenCV 4.x for 8-bit images:
+
+  resize (imgproc/resize.cpp, resizeGeneric_ with HResizeLinear / VResizeLinear<uchar>):
+    per destination column dx: fx = (float)((dx + 0.5) * (src_w / dst_w) - 0.5); sx = floor(fx);
+    fx -= sx; taps clamped into the image with fx = 0; weights cvRound((1 - fx) * 2048) and
+    cvRound(fx * 2048), each rounded on its own (float32 arithmetic, round half to even); rows the
+    same, except that row indices are clamped and the weights kept;
+    horizontal pass D = S[sx] * a0 + S[sx+1] * a1 (int32);
+    vertical pass   dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2
+    (an exact 2x reduction is routed to INTER_AREA by cv.resize, which gives the same bytes);
+  gray (imgproc/color_rgb.simd.hpp, RGB2Gray<uchar>, the 15-bit coefficients of OpenCV >= 4.x):
+    (B * 3735 + G * 19235 + R * 9798 + 16384) >> 15.
+
+PARITY WITH cv2 IS UNPINNED (no OpenCV here to compare with): the stated expectation is bit
+equality for every scale; a build of OpenCV that dispatches 8-bit resize to IPP / another HAL, or
+the older 14-bit gray coefficients (4899, 9617, 1868, >> 14; OpenCV 3.x), can differ by one gray
+code on isolated pixels.  The device path (amvs_set_view_bgr8, csrc/amvs_prep.hip) is bit-identical to
+this file.  At scale 1.0 the resize is a copy in all of them.
 """
 import numpy as np
 
@@ -15,43 +31,48 @@ except Exception:  # noqa: BLE001
     _cv = None
 
 
+def _axis_tables(n_dst, n_src, clamp_taps):
+    """(offsets, w0, w1) of OpenCV's linear resize for one axis (float32 arithmetic as there)."""
+    scale = 1.0 / (n_dst / n_src)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    if clamp_taps:
+        lo, hi = s < 0, s >= n_src - 1
+        f[lo | hi] = np.float32(0.0)
+        s[lo] = 0
+        s[hi] = n_src - 1
+    w0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int32)
+    w1 = np.rint(f * np.float32(2048.0)).astype(np.int32)
+    return s, w0, w1
+
+
 def _resize_linear_u8(img, new_w, new_h):
-    """cv.resize(..., INTER_LINEAR) restated: half-pixel centres, clamped taps, 11-bit
-    fixed-point weights, rounding as OpenCV's 8-bit path."""
+    """cv.resize(img, (new_w, new_h)) for 8-bit images, INTER_LINEAR (see the module docstring)."""
     h, w = img.shape[:2]
     if (new_w, new_h) == (w, h):
         return img.copy()
-
-    def axis(n_dst, n_src):
-        pos = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
-        i0 = np.floor(pos).astype(np.int64)
-        frac = pos - i0
-        frac[i0 < 0] = 0.0
-        i0 = np.clip(i0, 0, n_src - 1)
-        i1 = np.clip(i0 + 1, 0, n_src - 1)
-        w1 = np.rint(frac * 2048).astype(np.int64)
-        return i0, i1, 2048 - w1, w1
-
-    x0, x1, wx0, wx1 = axis(new_w, w)
-    y0, y1, wy0, wy1 = axis(new_h, h)
-    src = img.astype(np.int64)
+    x0, a0, a1 = _axis_tables(new_w, w, True)
+    y0, b0, b1 = _axis_tables(new_h, h, False)
+    x1 = np.minimum(x0 + 1, w - 1)
+    src = img.astype(np.int32)
     if src.ndim == 2:
         src = src[:, :, None]
-    rows = src[:, x0, :] * wx0[None, :, None] + src[:, x1, :] * wx1[None, :, None]
-    out = rows[y0] * wy0[:, None, None] + rows[y1] * wy1[:, None, None]
-    out = (out + (1 << 21)) >> 22
-    out = np.clip(out, 0, 255).astype(np.uint8)
+    rows = src[:, x0, :] * a0[None, :, None] + src[:, x1, :] * a1[None, :, None]
+    r0 = rows[np.clip(y0, 0, h - 1)] >> 4
+    r1 = rows[np.clip(y0 + 1, 0, h - 1)] >> 4
+    out = (((b0[:, None, None] * r0) >> 16) + ((b1[:, None, None] * r1) >> 16) + 2) >> 2
+    out = out.astype(np.uint8)
     return out[:, :, 0] if img.ndim == 2 else out
 
 
 def _bgr_to_gray_u8(img):
-    """cv.cvtColor(BGR2GRAY) for 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14."""
-    # (32-bit arithmetic: the sum is below 2^22)
-    acc = img[:, :, 0].astype(np.uint32) * np.uint32(1868)
-    acc += img[:, :, 1].astype(np.uint32) * np.uint32(9617)
-    acc += img[:, :, 2].astype(np.uint32) * np.uint32(4899)
-    acc += np.uint32(8192)
-    acc >>= np.uint32(14)
+    """cv.cvtColor(BGR2GRAY) for 8-bit: (B*3735 + G*19235 + R*9798 + 16384) >> 15."""
+    acc = img[:, :, 0].astype(np.uint32) * np.uint32(3735)
+    acc += img[:, :, 1].astype(np.uint32) * np.uint32(19235)
+    acc += img[:, :, 2].astype(np.uint32) * np.uint32(9798)
+    acc += np.uint32(16384)
+    acc >>= np.uint32(15)
     return acc.astype(np.uint8)
 
 

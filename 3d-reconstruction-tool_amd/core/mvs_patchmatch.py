@@ -76,7 +76,8 @@ class PatchMatchMVS:
                  num_iterations: int = 3, num_samples: int = 8, min_views: int = 3,
                  depth_min: float = 0.1, depth_max: float = 100.0, *,
                  seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
-                 process_group=None, device_fusion: bool = True, mode: str = "fast"):
+                 process_group=None, device_fusion: bool = True, mode: str = "fast",
+                 device_prep: bool = True):
         self.camera = camera
         self.scale = scale
         self.patch_size = patch_size
@@ -89,6 +90,7 @@ class PatchMatchMVS:
         self.views_per_batch = max(1, int(views_per_batch))
         self.process_group = process_group
         self.device_fusion = device_fusion
+        self.device_prep = device_prep           # resize / gray conversion on the GPU (amvs_set_view_bgr8)
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         self.mode = mode
@@ -120,7 +122,10 @@ class PatchMatchMVS:
         self._estimate_depth_range(poses, sparse_points)
         print(f"  Depth range: [{self.depth_min:.2f}, {self.depth_max:.2f}]")
         print("\nPreparing images...")
-        proc_images = self._prepare_images(images, cam_indices)
+        if self.device_prep:
+            proc_images = self._prepare_images_device(images, cam_indices, poses)
+        else:
+            proc_images = self._prepare_images(images, cam_indices)
 
         print(f"\nComputing depth maps for {n_cams} views...")
         jobs = []
@@ -186,6 +191,34 @@ class PatchMatchMVS:
         prepared = prepare_views([images[idx]["image"] for idx in indices], self.scale)
         return dict(zip(indices, prepared))
 
+    def _prepare_images_device(self, images: List[dict], indices: List[int], poses: Dict[int, CameraPose]) -> Dict:
+        """_prepare_images on the GPU: every view's 8-bit BGR image is uploaded as it is (3 B/pixel) and
+        resized / converted there (amvs_set_view_bgr8), which also leaves it resident for the sweep.
+        Returns the prepared dict without host gray maps ('gray': None); the engine is cached for it."""
+        h, w = images[indices[0]]["image"].shape[:2]
+        H, W = int(h * self.scale), int(w * self.scale)
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id)
+        self._slot = {idx: s for s, idx in enumerate(indices)}
+        prepared = {}
+        for idx in indices:
+            img = images[idx]["image"]
+            if img.shape[:2] != (h, w):
+                raise ValueError("all views must share one size")
+            color = eng.set_view_bgr8(self._slot[idx], img, poses[idx].R, poses[idx].t)
+            prepared[idx] = {"color": color, "gray": None, "shape": (H, W)}
+        self._engine, self._engine_images = eng, prepared
+        self._engine_key = self._make_engine_key(prepared, poses, indices)
+        return prepared
+
+    def _make_engine_key(self, images: Dict, poses: Dict[int, CameraPose], indices: List[int]):
+        H, W = images[indices[0]]["shape"]
+        pose_print = b"".join(np.asarray(poses[i].R, np.float64).tobytes() + np.asarray(poses[i].t, np.float64).tobytes()
+                              for i in indices)
+        return (tuple(indices), (int(H), int(W)), pose_print, self.K_scaled.tobytes(), self.device_id)
+
     def _select_source_views(self, ref_idx: int, all_indices: List[int],
                              poses: Dict[int, CameraPose], k: int = 4) -> List[int]:
         """Score = baseline * (1 - |angle-20|/60) for 5 < angle < 60 degrees, else 0; the k best
@@ -215,9 +248,7 @@ class PatchMatchMVS:
         freed dict can be reused by CPython) and a fingerprint of every R|t, so a second call with
         refined poses re-uploads instead of sweeping with stale ones."""
         H, W = images[indices[0]]["shape"]
-        pose_print = b"".join(np.asarray(poses[i].R, np.float64).tobytes() + np.asarray(poses[i].t, np.float64).tobytes()
-                              for i in indices)
-        key = (tuple(indices), (int(H), int(W)), pose_print, self.K_scaled.tobytes(), self.device_id)
+        key = self._make_engine_key(images, poses, indices)
         if self._engine is not None and self._engine_images is images and self._engine_key == key:
             return self._engine
         if self._engine is not None:

@@ -62,6 +62,8 @@ struct amvs_ctx {
     int cap_planes = 0;
     unsigned *d_keys = nullptr;          // plane-sweep running best, [slot][H*W]
     int cap_keys = 0;
+    float *d_sweep_depth = nullptr, *d_sweep_conf = nullptr;   // maps of the last amvs_plane_sweep_batch
+    int cap_sweep = 0, n_sweep = 0;
     double *d_cloud_pts = nullptr;       // result of the last amvs_fuse_filter
     unsigned char *d_cloud_rgb = nullptr;
     long long cloud_n = 0;
@@ -480,6 +482,8 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
+    if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
     if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
     if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
     if (c->d_images) (void)hipFree(c->d_images);
@@ -531,6 +535,81 @@ static int set_view_common(amvs_ctx *c, int view, const void *gray, const float 
                                       c->d_pairs + view * c->pstride, c->d_flag, c->stream));
     HIPCHK(c, hipMemcpyAsync(&inexact, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->exact8[view] = inexact ? 0 : 1;
+    std::memcpy(c->R[view].data(), R, 36);
+    std::memcpy(c->t[view].data(), t, 12);
+    c->have[view] = 1;
+    for (auto &kv : c->stats) if (!kv.second.done.empty()) kv.second.done[view] = 0;
+    for (auto &kv : c->fstats) if (!kv.second.done.empty()) kv.second.done[view] = 0;
+    return AMVS_OK;
+}
+
+// OpenCV's linear-resize tables for one axis (resize.cpp, resizeGeneric_ setup, ksize = 2): float32
+// arithmetic as there; cvRound = round half to even
+static void resize_axis_tables(int n_dst, int n_src, std::vector<int> &ofs, std::vector<short> &w, bool clamp_ofs)
+{
+    const double scale = 1.0 / ((double)n_dst / (double)n_src);
+    ofs.resize(n_dst); w.resize(2 * (size_t)n_dst);
+    for (int d = 0; d < n_dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (clamp_ofs) {                       // columns: taps clamped into the image, weight zeroed
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+        }
+        ofs[d] = s;                            // rows: the kernel clamps the two row indices, weights stay
+        const float c0 = 1.f - f, c1 = f;
+        w[2 * d] = (short)std::nearbyint(c0 * 2048.f);
+        w[2 * d + 1] = (short)std::nearbyint(c1 * 2048.f);
+    }
+}
+
+int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h, int src_w, const float R[9],
+                       const float t[3], uint8_t *scaled_bgr_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (view < 0 || view >= c->n_views || !bgr_host || !R || !t || src_h < 1 || src_w < 1)
+        return fail(c, AMVS_EINVAL, "bad view argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t n_src = (size_t)src_h * src_w, n_dst = (size_t)c->H * c->W;
+    std::vector<int> xofs, yofs;
+    std::vector<short> ialpha, ibeta;
+    resize_axis_tables(c->W, src_w, xofs, ialpha, true);
+    resize_axis_tables(c->H, src_h, yofs, ibeta, false);
+    unsigned char *d_src = nullptr, *d_scaled = nullptr;
+    int *d_tab = nullptr;
+    const size_t tab_ints = (size_t)c->W + c->H, tab_shorts = 2 * ((size_t)c->W + c->H);
+    auto cleanup = [&]() {
+        if (d_src) (void)hipFree(d_src);
+        if (d_scaled) (void)hipFree(d_scaled);
+        if (d_tab) (void)hipFree(d_tab);
+    };
+    hipError_t e = hipMalloc(&d_src, 3 * n_src);
+    if (e == hipSuccess) e = hipMalloc(&d_scaled, 3 * n_dst);
+    if (e == hipSuccess) e = hipMalloc(&d_tab, 4 * tab_ints + 2 * tab_shorts);
+    int *d_xofs = d_tab, *d_yofs = d_tab ? d_tab + c->W : nullptr;
+    short *d_ialpha = d_tab ? (short *)(d_tab + tab_ints) : nullptr, *d_ibeta = d_ialpha ? d_ialpha + 2 * c->W : nullptr;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_src, bgr_host, 3 * n_src, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xofs, xofs.data(), 4 * (size_t)c->W, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_yofs, yofs.data(), 4 * (size_t)c->H, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ialpha, ialpha.data(), 4 * (size_t)c->W, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ibeta, ibeta.data(), 4 * (size_t)c->H, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess)
+        e = amvs::launch_prep_bgr8(d_src, src_h, src_w, c->H, c->W, d_xofs, d_ialpha, d_yofs, d_ibeta, d_scaled,
+                                   c->d_images + view * c->stride, c->stream);
+    if (e == hipSuccess && scaled_bgr_out)
+        e = hipMemcpyAsync(scaled_bgr_out, d_scaled, 3 * n_dst, hipMemcpyDeviceToHost, c->stream);
+    int inexact = 0;
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream);
+    if (e == hipSuccess)
+        e = amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W, c->d_pairs + view * c->pstride, c->d_flag,
+                                    c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&inexact, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("set_view_bgr8: ") + hipGetErrorString(e));
     c->exact8[view] = inexact ? 0 : 1;
     std::memcpy(c->R[view].data(), R, 36);
     std::memcpy(c->t[view].data(), t, 12);
@@ -811,6 +890,122 @@ int amvs_plane_sweep(amvs_ctx *c, int ref, const int *nbr_ids, int n_nbr, const 
     resolve_timing(c);
     return AMVS_OK;
 }
+
+int amvs_plane_sweep_batch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
+                           const float *depths, int D, int patch_size, float thresh)
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_ref <= 0) return fail(c, AMVS_EINVAL, "empty batch");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    if (n_ref > c->cap_sweep) {
+        if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
+        if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
+        c->d_sweep_depth = c->d_sweep_conf = nullptr; c->cap_sweep = 0;
+        HIPCHK(c, hipMalloc(&c->d_sweep_depth, 4 * hw * n_ref));
+        HIPCHK(c, hipMalloc(&c->d_sweep_conf, 4 * hw * n_ref));
+        c->cap_sweep = n_ref;
+    }
+    c->n_sweep = 0;
+    rc = amvs_plane_sweep_device(c, n_ref, ref_ids, nbr_ids, n_nbr, depths, D, patch_size, thresh,
+                                 c->d_sweep_depth, c->d_sweep_conf);
+    if (rc) return rc;
+    c->n_sweep = n_ref;
+    return AMVS_OK;
+}
+
+int amvs_fetch_sweep_maps(amvs_ctx *c, int first, int count, float *depth_out, float *conf_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (first < 0 || count < 0 || first + count > c->n_sweep || !depth_out || !conf_out)
+        return fail(c, AMVS_EINVAL, "sweep maps out of range (run amvs_plane_sweep_batch first)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, hipMemcpyAsync(depth_out, c->d_sweep_depth + first * hw, 4 * hw * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(conf_out, c->d_sweep_conf + first * hw, 4 * hw * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    return AMVS_OK;
+}
+
+int amvs_stereo_backproject(amvs_ctx *c, int n_maps, const void *depth, const void *conf, int maps_where,
+                            const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
+                            float min_confidence, int64_t *per_map_counts, int64_t *total)
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_maps < 1 || !colors_bgr_host || !K_inv || !poses || !total || maps_where < 0 || maps_where > 2)
+        return fail(c, AMVS_EINVAL, "bad argument");
+    if (maps_where == 2 ? n_maps != c->n_sweep : (!depth || !conf))
+        return fail(c, AMVS_EINVAL, maps_where == 2 ? "n_maps differs from the resident plane-sweep batch" : "NULL maps");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W, n = hw * (size_t)n_maps;
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    c->d_cloud_pts = nullptr; c->d_cloud_rgb = nullptr; c->cloud_n = 0;
+    float *dd = nullptr, *dc = nullptr;
+    unsigned char *dbgr = nullptr;
+    hipError_t e = hipMalloc(&dbgr, 3 * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbgr, colors_bgr_host, 3 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && maps_where == 0) {
+        e = hipMalloc(&dd, 4 * n);
+        if (e == hipSuccess) e = hipMalloc(&dc, 4 * n);
+        if (e == hipSuccess) e = hipMemcpyAsync(dd, depth, 4 * n, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc, conf, 4 * n, hipMemcpyHostToDevice, c->stream);
+    } else if (e == hipSuccess) {
+        dd = maps_where == 2 ? c->d_sweep_depth : (float *)depth;
+        dc = maps_where == 2 ? c->d_sweep_conf : (float *)conf;
+    }
+    long long tot = 0;
+    std::vector<long long> per(n_maps, 0);
+    if (e == hipSuccess)
+        e = amvs::stereo_backproject(dd, dc, dbgr, n_maps, c->H, c->W, K_inv, poses, min_confidence, &c->d_cloud_pts,
+                                     &c->d_cloud_rgb, &tot, per.data(), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    if (maps_where == 0) { if (dd) (void)hipFree(dd); if (dc) (void)hipFree(dc); }
+    if (dbgr) (void)hipFree(dbgr);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("stereo_backproject: ") + hipGetErrorString(e));
+    c->cloud_n = tot;
+    *total = tot;
+    if (per_map_counts) for (int j = 0; j < n_maps; ++j) per_map_counts[j] = per[j];
+    return AMVS_OK;
+}
+
+int amvs_cloud_knn_mean_distance(amvs_ctx *c, int k, double *mean_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!mean_out || c->cloud_n < 1) return fail(c, AMVS_EINVAL, "no resident cloud / NULL output");
+    if (!amvs::knn_supported(k)) return fail(c, AMVS_EUNSUPPORTED, "k not compiled in (8, 10, 16, 20, 32)");
+    if (c->cloud_n < k) return fail(c, AMVS_EINVAL, "fewer points than neighbours");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, amvs::knn_mean_distance(c->d_cloud_pts, c->cloud_n, k, mean_out, c->stream, true));
+    return AMVS_OK;
+}
+
+int amvs_cloud_voxel_downsample(amvs_ctx *c, const uint8_t *keep_mask, double voxel_size, int64_t *count)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!count || !(voxel_size > 0.0)) return fail(c, AMVS_EINVAL, "bad argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    double *p2 = nullptr;
+    unsigned char *r2 = nullptr;
+    long long m = 0;
+    if (c->cloud_n > 0) {
+        hipError_t e = amvs::voxel_downsample(c->d_cloud_pts, c->d_cloud_rgb, c->cloud_n, keep_mask, voxel_size, &p2, &r2,
+                                              &m, c->stream);
+        if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("voxel_downsample: ") + hipGetErrorString(e));
+        (void)hipFree(c->d_cloud_pts); (void)hipFree(c->d_cloud_rgb);
+    }
+    c->d_cloud_pts = p2; c->d_cloud_rgb = r2; c->cloud_n = m;
+    *count = m;
+    return AMVS_OK;
+}
+
+int amvs_knn_supported(int k) { return amvs::knn_supported(k) ? 1 : 0; }
 
 int amvs_eval_cost(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size,
                    const float *depth_in, float *cost_out)

@@ -32,6 +32,30 @@ __global__ __launch_bounds__(256) void fuse_flag_kernel(const float *__restrict_
         flag[i] = conf[i] >= min_views ? 1 : 0;
 }
 
+// stereo: confidence >= min_confidence and depth > 0 (dense_stereo.py:414)
+__global__ __launch_bounds__(256) void stereo_flag_kernel(const float *__restrict__ conf, const float *__restrict__ depth,
+                                                          long long n, float min_conf, unsigned char *__restrict__ flag)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        flag[i] = (conf[i] >= min_conf) & (depth[i] > 0.0f) ? 1 : 0;
+}
+
+// first[j] = number of selected (ascending) indices below j*HW, j = 0 .. n_maps  (lower bounds)
+__global__ void map_bounds_kernel(const long long *__restrict__ sel, long long m, long long HW, int n_maps,
+                                  long long *__restrict__ first)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n_maps) return;
+    const long long key = (long long)j * HW;
+    long long lo = 0, hi = m;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (sel[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    first[j] = lo;
+}
+
 // back-project the selected pixels: rays = [x,y,1] @ K_inv.T; X = rays*d; Xw = (X - t) @ R
 // (mvs_patchmatch.py:556-562), all float64
 __global__ __launch_bounds__(256) void fuse_project_kernel(const long long *__restrict__ sel, long long m,
@@ -170,6 +194,51 @@ hipError_t sort_keys(double *in, double *out, long long n, Scratch &tmp, hipStre
     return hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, in, out, (int)n, 0, 64, st);
 }
 
+// First point of every voxel in key order (np.unique(keys, return_index=True)) among the points
+// sel[0 .. m2) of (pts, rgb): stable radix sort of the int64 keys, heads of the runs, gather.
+hipError_t voxel_first_of_key(const double *pts, const unsigned char *rgb, const long long *sel, long long m2,
+                              double voxel, Scratch &tmp, Scratch &flag, Scratch &cnt, double **pts2_out,
+                              unsigned char **rgb2_out, long long *m3_out, hipStream_t st)
+{
+    *pts2_out = nullptr; *rgb2_out = nullptr; *m3_out = 0;
+    Scratch keysA, keysB, idxA, idxB, pick;
+    FCHK(keysA.need(8 * m2)); FCHK(keysB.need(8 * m2)); FCHK(idxA.need(8 * m2)); FCHK(idxB.need(8 * m2));
+    FCHK(pick.need(8 * m2));
+    FCHK(flag.need(m2));
+    hipLaunchKernelGGL(voxel_key_kernel, grid_for(m2), dim3(256), 0, st, pts, sel, m2, voxel, (long long *)keysA.p);
+    hipLaunchKernelGGL(iota_kernel, grid_for(m2), dim3(256), 0, st, (long long *)idxA.p, m2);
+    {
+        size_t bytes = 0;
+        FCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (long long *)keysA.p, (long long *)keysB.p,
+                                                (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st));
+        FCHK(tmp.need(bytes));
+        FCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, (long long *)keysA.p, (long long *)keysB.p,
+                                                (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st));
+    }
+    hipLaunchKernelGGL(run_head_kernel, grid_for(m2), dim3(256), 0, st, (const long long *)keysB.p, m2, (unsigned char *)flag.p);
+    long long m3 = 0;
+    {   // positions (in sorted order) of the run heads -> original indices idxB[pos]
+        size_t bytes = 0;
+        FCHK(hipcub::DeviceSelect::Flagged(nullptr, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
+                                           (long long *)pick.p, (long long *)cnt.p, (int)m2, st));
+        FCHK(tmp.need(bytes));
+        FCHK(hipcub::DeviceSelect::Flagged(tmp.p, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
+                                           (long long *)pick.p, (long long *)cnt.p, (int)m2, st));
+        FCHK(hipMemcpyAsync(&m3, cnt.p, 8, hipMemcpyDeviceToHost, st));
+        FCHK(hipStreamSynchronize(st));
+    }
+    double *pts2 = nullptr;
+    unsigned char *rgb2 = nullptr;
+    FCHK(hipMalloc(&pts2, sizeof(double) * 3 * (m3 > 0 ? m3 : 1)));
+    hipError_t e = hipMalloc(&rgb2, 3 * (m3 > 0 ? m3 : 1));
+    if (e != hipSuccess) { (void)hipFree(pts2); return e; }
+    hipLaunchKernelGGL(gather_kernel, grid_for(m3), dim3(256), 0, st, pts, rgb, sel, (const long long *)pick.p, m3, pts2, rgb2);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(pts2); (void)hipFree(rgb2); return e; }
+    *pts2_out = pts2; *rgb2_out = rgb2; *m3_out = m3;
+    return hipSuccess;
+}
+
 // np.median of a sorted column
 double median_sorted(const std::vector<double> &mid, long long n) { return n % 2 ? mid[0] : (mid[0] + mid[1]) / 2.0; }
 
@@ -255,45 +324,87 @@ hipError_t fuse_filter(const float *depth, const float *conf, const unsigned cha
     if (m2 == 0) { (void)hipFree(pts); (void)hipFree(rgb); counts[1] = 0; return hipSuccess; }
 
     // ---- voxel de-duplication: first point of every key, in key order ----
-    Scratch keysA, keysB, idxA, idxB, pick;
-    if ((e = keysA.need(8 * m2)) != hipSuccess || (e = keysB.need(8 * m2)) != hipSuccess ||
-        (e = idxA.need(8 * m2)) != hipSuccess || (e = idxB.need(8 * m2)) != hipSuccess ||
-        (e = pick.need(8 * m2)) != hipSuccess) return bail(e);
-    hipLaunchKernelGGL(voxel_key_kernel, grid_for(m2), dim3(256), 0, st, pts, (const long long *)sel.p, m2, 0.01,
-                       (long long *)keysA.p);
-    hipLaunchKernelGGL(iota_kernel, grid_for(m2), dim3(256), 0, st, (long long *)idxA.p, m2);
-    {
-        size_t bytes = 0;
-        if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (long long *)keysA.p, (long long *)keysB.p,
-                                                    (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st)) != hipSuccess) return bail(e);
-        if ((e = tmp.need(bytes)) != hipSuccess) return bail(e);
-        if ((e = hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, (long long *)keysA.p, (long long *)keysB.p,
-                                                    (long long *)idxA.p, (long long *)idxB.p, (int)m2, 0, 64, st)) != hipSuccess) return bail(e);
-    }
-    hipLaunchKernelGGL(run_head_kernel, grid_for(m2), dim3(256), 0, st, (const long long *)keysB.p, m2, (unsigned char *)flag.p);
-    long long m3 = 0;
-    {   // positions (in sorted order) of the run heads -> original indices idxB[pos]
-        size_t bytes = 0;
-        if ((e = hipcub::DeviceSelect::Flagged(nullptr, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
-                                               (long long *)pick.p, (long long *)cnt.p, (int)m2, st)) != hipSuccess) return bail(e);
-        if ((e = tmp.need(bytes)) != hipSuccess) return bail(e);
-        if ((e = hipcub::DeviceSelect::Flagged(tmp.p, bytes, (long long *)idxB.p, (unsigned char *)flag.p,
-                                               (long long *)pick.p, (long long *)cnt.p, (int)m2, st)) != hipSuccess) return bail(e);
-        if ((e = hipMemcpyAsync(&m3, cnt.p, 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return bail(e);
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return bail(e);
-    }
     double *pts2 = nullptr;
     unsigned char *rgb2 = nullptr;
-    if ((e = hipMalloc(&pts2, sizeof(double) * 3 * m3)) != hipSuccess) return bail(e);
-    if ((e = hipMalloc(&rgb2, 3 * m3)) != hipSuccess) { (void)hipFree(pts2); return bail(e); }
-    hipLaunchKernelGGL(gather_kernel, grid_for(m3), dim3(256), 0, st, pts, rgb, (const long long *)sel.p,
-                       (const long long *)pick.p, m3, pts2, rgb2);
-    e = hipStreamSynchronize(st);
+    long long m3 = 0;
+    e = voxel_first_of_key(pts, rgb, (const long long *)sel.p, m2, 0.01, tmp, flag, cnt, &pts2, &rgb2, &m3, st);
     (void)hipFree(pts); (void)hipFree(rgb);
-    if (e != hipSuccess) { (void)hipFree(pts2); (void)hipFree(rgb2); return e; }
+    if (e != hipSuccess) return e;
     *pts_out = pts2; *rgb_out = rgb2;
     counts[1] = m3;
     return hipSuccess;
+}
+
+// DenseStereoReconstructor._backproject (dense_stereo.py:407-437) for n_maps reference views at once:
+// pixels with confidence >= min_confidence and depth > 0, view by view in row-major order, through
+// the same float64 chain as fuse_project_kernel (float32 pixel coordinates convert exactly).
+// per_map_h[j] (host, optional) = points of map j -- the counts of the reference's progress lines.
+hipError_t stereo_backproject(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
+                              const double *Kinv_h, const double *poses_h, float min_confidence, double **pts_out,
+                              unsigned char **rgb_out, long long *total, long long *per_map_h, hipStream_t st)
+{
+    *pts_out = nullptr; *rgb_out = nullptr; *total = 0;
+    const long long HW = (long long)H * W, n = (long long)n_maps * HW;
+    if (n <= 0 || n > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    Scratch tmp, flag, sel, consts, cnt, bounds;
+    FCHK(flag.need(n));
+    FCHK(sel.need(sizeof(long long) * n));
+    FCHK(consts.need(sizeof(double) * (9 + 12 * n_maps)));
+    FCHK(cnt.need(sizeof(long long)));
+    FCHK(bounds.need(sizeof(long long) * (n_maps + 1)));
+    double *d_Kinv = (double *)consts.p, *d_poses = d_Kinv + 9;
+    FCHK(hipMemcpyAsync(d_Kinv, Kinv_h, sizeof(double) * 9, hipMemcpyHostToDevice, st));
+    FCHK(hipMemcpyAsync(d_poses, poses_h, sizeof(double) * 12 * n_maps, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(stereo_flag_kernel, grid_for(n), dim3(256), 0, st, conf, depth, n, min_confidence,
+                       (unsigned char *)flag.p);
+    long long m = 0;
+    FCHK(select_indices((unsigned char *)flag.p, n, (long long *)sel.p, (long long *)cnt.p, &m, tmp, st));
+    *total = m;
+    if (per_map_h) {
+        std::vector<long long> first(n_maps + 1, 0);
+        hipLaunchKernelGGL(map_bounds_kernel, dim3((n_maps + 1 + 63) / 64), dim3(64), 0, st, (const long long *)sel.p, m, HW,
+                           n_maps, (long long *)bounds.p);
+        FCHK(hipMemcpyAsync(first.data(), bounds.p, sizeof(long long) * (n_maps + 1), hipMemcpyDeviceToHost, st));
+        FCHK(hipStreamSynchronize(st));
+        for (int j = 0; j < n_maps; ++j) per_map_h[j] = first[j + 1] - first[j];
+    }
+    if (m == 0) return hipSuccess;
+    double *pts = nullptr;
+    unsigned char *rgb = nullptr;
+    FCHK(hipMalloc(&pts, sizeof(double) * 3 * m));
+    hipError_t e = hipMalloc(&rgb, 3 * m);
+    if (e != hipSuccess) { (void)hipFree(pts); return e; }
+    hipLaunchKernelGGL(fuse_project_kernel, grid_for(m), dim3(256), 0, st, (const long long *)sel.p, m, depth, bgr, H,
+                       W, d_Kinv, d_poses, pts, rgb);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(pts); (void)hipFree(rgb); return e; }
+    *pts_out = pts; *rgb_out = rgb;
+    return hipSuccess;
+}
+
+// DenseStereoReconstructor._voxel_down_sample (dense_stereo.py:475-492) of a device cloud, after an
+// optional keep mask (host, m bytes; the outlier filter's selection): first point of every voxel in
+// key order.  The reference casts the voxel indices through int32 before forming the int64 key; for
+// clouds inside +-2^31 voxels that is the identity.
+hipError_t voxel_downsample(const double *pts, const unsigned char *rgb, long long m, const unsigned char *keep_h,
+                            double voxel, double **pts_out, unsigned char **rgb_out, long long *m_out, hipStream_t st)
+{
+    *pts_out = nullptr; *rgb_out = nullptr; *m_out = 0;
+    if (m <= 0) return hipSuccess;
+    if (m > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    Scratch tmp, flag, sel, cnt;
+    FCHK(flag.need(m));
+    FCHK(sel.need(sizeof(long long) * m));
+    FCHK(cnt.need(sizeof(long long)));
+    long long m2 = m;
+    if (keep_h) {
+        FCHK(hipMemcpyAsync(flag.p, keep_h, m, hipMemcpyHostToDevice, st));
+        FCHK(select_indices((unsigned char *)flag.p, m, (long long *)sel.p, (long long *)cnt.p, &m2, tmp, st));
+    } else {
+        hipLaunchKernelGGL(iota_kernel, grid_for(m), dim3(256), 0, st, (long long *)sel.p, m);
+    }
+    if (m2 == 0) return hipSuccess;
+    return voxel_first_of_key(pts, rgb, (const long long *)sel.p, m2, voxel, tmp, flag, cnt, pts_out, rgb_out, m_out, st);
 }
 
 }  // namespace amvs

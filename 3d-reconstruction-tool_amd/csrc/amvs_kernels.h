@@ -90,7 +90,8 @@ struct SweepArgs : StepArgsBase {
 
 bool patch_supported(int K);
 bool knn_supported(int k);
-hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st);
+hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st,
+                             bool points_on_device = false);
 int strip_out_width(int K);
 int step_waves_per_cu(int K, int S, bool u8);
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
@@ -131,5 +132,18 @@ hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw
 hipError_t fuse_filter(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
                        const double *Kinv_h, const double *poses_h, float min_views, bool do_filter,
                        double **pts_out, unsigned char **rgb_out, long long counts[2], hipStream_t st);
+
+// amvs_prep.hip: cv.resize (INTER_LINEAR, 8-bit BGR) + cvtColor(BGR2GRAY) / 255 of one view; the
+// weight tables are built on the host (amvs_capi.hip, OpenCV's float32 arithmetic)
+hipError_t launch_prep_bgr8(const unsigned char *src, int sh, int sw, int dh, int dw, const int *xofs,
+                            const short *ialpha, const int *yofs, const short *ibeta, unsigned char *scaled,
+                            float *gray, hipStream_t st);
+
+// amvs_fusion.hip: the stereo path's post-steps (dense_stereo.py:407-437, 475-492)
+hipError_t stereo_backproject(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
+                              const double *Kinv_h, const double *poses_h, float min_confidence, double **pts_out,
+                              unsigned char **rgb_out, long long *total, long long *per_map_h, hipStream_t st);
+hipError_t voxel_downsample(const double *pts, const unsigned char *rgb, long long m, const unsigned char *keep_h,
+                            double voxel, double **pts_out, unsigned char **rgb_out, long long *m_out, hipStream_t st);
 
 }  // namespace amvs

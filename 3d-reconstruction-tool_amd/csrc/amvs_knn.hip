@@ -340,8 +340,9 @@ hipError_t launch_query(const double *sorted, long long n, const Grid &gr, const
 
 bool knn_supported(int k) { return k == 8 || k == 10 || k == 16 || k == 20 || k == 32; }
 
-// points: host [n][3] float64; mean_out: host [n].  Needs n >= k.
-hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st)
+// points: [n][3] float64 on the host (or on the device: points_on_device); mean_out: host [n].  Needs n >= k.
+hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st,
+                             bool points_on_device)
 {
     // The grid spans the 1st .. 99th percentile of every axis (estimated on a strided sample); points
     // outside are binned into the border cells (per-axis clamping only under-estimates coordinate
@@ -351,11 +352,24 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     double lo[3], hi[3];
     {
         const long long stride = std::max<long long>(1, n / 65536);
+        const long long cnt = (n + stride - 1) / stride;
+        // the strided sample on the host (a device-resident cloud is sampled with one strided copy:
+        // dereferencing device memory from the host works through the PCIe BAR but takes ~4 us per read)
+        std::vector<double> sample((size_t)(3 * cnt));
+        if (points_on_device) {
+            hipError_t e = hipMemcpy2DAsync(sample.data(), 24, points, (size_t)stride * 24, 24, (size_t)cnt,
+                                            hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+        } else {
+            for (long long j = 0; j < cnt; ++j)
+                for (int a = 0; a < 3; ++a) sample[(size_t)(3 * j + a)] = points[3 * j * stride + a];
+        }
         std::vector<double> axis;
-        axis.reserve((size_t)(n / stride + 1));
+        axis.reserve((size_t)cnt);
         for (int a = 0; a < 3; ++a) {
             axis.clear();
-            for (long long i = 0; i < n; i += stride) axis.push_back(points[3 * i + a]);
+            for (long long j = 0; j < cnt; ++j) axis.push_back(sample[(size_t)(3 * j + a)]);
             const size_t m = axis.size(), lo_k = (m - 1) / 100, hi_k = (m - 1) - lo_k;
             std::nth_element(axis.begin(), axis.begin() + lo_k, axis.end());
             lo[a] = axis[lo_k];
@@ -398,7 +412,8 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     KCHK_C(hipMalloc(&d_origin, sizeof(int) * n));
     KCHK_C(hipMalloc(&d_pending, (size_t)n));
     KCHK_C(hipMalloc(&d_occ, sizeof(int)));
-    KCHK_C(hipMemcpyAsync(d_pts, points, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    KCHK_C(hipMemcpyAsync(d_pts, points, sizeof(double) * 3 * n,
+                          points_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     KCHK_C(hipMemsetAsync(d_pending, 1, (size_t)n, st));
 
     const int bx = (int)std::min<long long>((n + 255) / 256, 4096);
@@ -468,7 +483,7 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     }
     // coarser levels (edge x2 each) pick up the queries whose neighbourhood is sparser than two
     // shells of the level before; the last level may scan
-    const bool debug = std::getenv("AMVS_KNN_DEBUG") != nullptr;
+    constexpr bool debug = false;            // per-level timings (development aid)
     int *d_iota = nullptr, *d_queries = nullptr, *d_nsel = nullptr;
     auto cleanup2 = [&]() {
         for (void *p : {(void *)d_iota, (void *)d_queries, (void *)d_nsel})

@@ -103,6 +103,21 @@ class Engine:
         t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))
         self._chk(self._lib.amvs_set_view(self._h, int(view), _p(gray), _p(R), _p(t)))
 
+    def set_view_bgr8(self, view, image_bgr_u8, R, t, want_color=True):
+        """Upload the 8-bit BGR image as it is and prepare it on the device (resize to the engine's
+        H x W, BGR -> gray, /255: mvs_patchmatch.py:167-191).  Returns the resized colour image
+        (H, W, 3) uint8, or None."""
+        img = np.ascontiguousarray(image_bgr_u8, dtype=np.uint8)
+        if img.ndim != 3 or img.shape[2] != 3:
+            raise ValueError("expected an (h, w, 3) uint8 BGR image")
+        R = _f32(np.asarray(R, np.float64).astype(np.float32).reshape(3, 3))
+        t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))
+        out = np.empty((self.H, self.W, 3), np.uint8) if want_color else None
+        self._chk(self._lib.amvs_set_view_bgr8(
+            self._h, int(view), img.ctypes.data_as(C.POINTER(C.c_uint8)), img.shape[0], img.shape[1], _p(R), _p(t),
+            out.ctypes.data_as(C.POINTER(C.c_uint8)) if want_color else None))
+        return out
+
     def set_view_device(self, view, gray_ptr, R, t):
         R = _f32(np.asarray(R, np.float64).astype(np.float32).reshape(3, 3))
         t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))
@@ -166,6 +181,80 @@ class Engine:
         self._chk(self._lib.amvs_plane_sweep_device(self._h, n, refp, nbrp, nbr.shape[1], _p(depths),
                                                     depths.size, int(patch_size), float(thresh),
                                                     C.c_void_p(depth_ptr), C.c_void_p(conf_ptr)))
+
+    def plane_sweep_batch(self, ref_ids, nbr_ids, depths, patch_size, thresh):
+        """All reference views in one launch; the maps stay in the context (fetch_sweep_maps,
+        stereo_backproject(resident=True))."""
+        ref, refp = _ids(ref_ids)
+        nbr, nbrp = _ids(nbr_ids)
+        n = ref.shape[0]
+        nbr = nbr.reshape(n, -1)
+        depths = _f32(np.asarray(depths, np.float64).astype(np.float32))
+        self._chk(self._lib.amvs_plane_sweep_batch(self._h, n, refp, nbrp, nbr.shape[1], _p(depths), depths.size,
+                                                   int(patch_size), float(thresh)))
+        return n
+
+    def fetch_sweep_maps(self, first, count):
+        d = np.empty((count, self.H, self.W), np.float32)
+        c = np.empty((count, self.H, self.W), np.float32)
+        self._chk(self._lib.amvs_fetch_sweep_maps(self._h, int(first), int(count), _p(d), _p(c)))
+        return d, c
+
+    # -- stereo post-steps on the device --------------------------------------
+    def stereo_backproject(self, colors_bgr, K_inv64, poses, min_confidence, depth=None, conf=None, fetch=False):
+        """dense_stereo.py:407-437 for all views at once.  depth / conf None: the resident maps of the
+        last plane_sweep_batch.  Returns (per-view point counts, total); the cloud stays on the device
+        (fetch=True additionally returns points, colours)."""
+        cols = np.ascontiguousarray(colors_bgr, dtype=np.uint8)
+        n = cols.shape[0]
+        cols = cols.reshape(n, self.H, self.W, 3)
+        kinv = np.ascontiguousarray(K_inv64, dtype=np.float64).reshape(9)
+        pp = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(R, np.float64).reshape(9),
+                                                            np.asarray(t, np.float64).reshape(3)])
+                                            for R, t in poses]))
+        if depth is None:
+            dptr, cptr, where = C.c_void_p(0), C.c_void_p(0), 2
+        else:
+            depth, conf = _f32(depth), _f32(conf)
+            dptr, cptr, where = depth.ctypes.data_as(C.c_void_p), conf.ctypes.data_as(C.c_void_p), 0
+        per = (C.c_int64 * n)()
+        total = C.c_int64(0)
+        self._chk(self._lib.amvs_stereo_backproject(
+            self._h, n, dptr, cptr, where, cols.ctypes.data_as(C.POINTER(C.c_uint8)),
+            kinv.ctypes.data_as(C.POINTER(C.c_double)), pp.ctypes.data_as(C.POINTER(C.c_double)),
+            float(min_confidence), per, C.byref(total)))
+        counts = [int(x) for x in per]
+        if not fetch:
+            return counts, int(total.value)
+        return (counts, int(total.value)) + self.fetch_cloud(int(total.value))
+
+    def fetch_cloud(self, m):
+        pts = np.empty((m, 3), np.float64)
+        rgb = np.empty((m, 3), np.uint8)
+        if m:
+            self._chk(self._lib.amvs_fetch_cloud(self._h, pts.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 rgb.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return pts, rgb
+
+    def cloud_knn_mean_distance(self, n_points, k=20):
+        out = np.empty(int(n_points), np.float64)
+        self._chk(self._lib.amvs_cloud_knn_mean_distance(self._h, int(k), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def cloud_voxel_downsample(self, voxel_size, keep_mask=None):
+        """dense_stereo.py:475-492 on the resident cloud (after the optional boolean keep mask);
+        returns the new point count."""
+        cnt = C.c_int64(0)
+        if keep_mask is None:
+            mp = None
+        else:
+            km = np.ascontiguousarray(keep_mask, dtype=np.uint8)
+            mp = km.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._chk(self._lib.amvs_cloud_voxel_downsample(self._h, mp, float(voxel_size), C.byref(cnt)))
+        return int(cnt.value)
+
+    def knn_supported(self, k):
+        return bool(self._lib.amvs_knn_supported(int(k)))
 
     # -- single steps (parity tests) ----------------------------------------
     def eval_cost(self, ref, src_ids, patch_size, depth):

@@ -98,6 +98,17 @@ int amvs_set_view(amvs_ctx *ctx, int view, const float *gray_host,
 int amvs_set_view_device(amvs_ctx *ctx, int view, const void *gray_device,
                          const float R[9], const float t[3]);
 
+/* _prepare_images (mvs_patchmatch.py:167-191, dense_stereo.py:156-176) of one view on the device: the
+ * undistorted 8-bit BGR image (src_h x src_w x 3, host; sfm_pipeline.py:114-120) is uploaded as it is
+ * (3 B/pixel), resized to the context's H x W with cv.resize's INTER_LINEAR fixed-point arithmetic,
+ * converted with cvtColor(BGR2GRAY)'s and divided by 255; the packed 8-bit map the sweeps sample is
+ * built from it directly.  scaled_bgr_out (optional, H x W x 3) receives the resized colour image the
+ * fusion takes its colours from.  The context must have been created with H = int(src_h * scale),
+ * W = int(src_w * scale).  OpenCV is absent from the build container: the arithmetic restates its
+ * published source and equals core/imageprep.py bit for bit; parity with cv2 itself is unpinned.   */
+int amvs_set_view_bgr8(amvs_ctx *ctx, int view, const uint8_t *bgr_host, int src_h, int src_w,
+                       const float R[9], const float t[3], uint8_t *scaled_bgr_out);
+
 /* PatchMatchMVS._patchmatch_cuda (mvs_patchmatch.py:225-321) for n_ref reference
  * views in one batch.  src_ids is [n_ref][n_src].  Outputs are [n_ref][H][W]
  * (depth, confidence) and [n_ref][H][W][3] (normal).  The RNG stream of a view is
@@ -136,6 +147,32 @@ int amvs_plane_sweep(amvs_ctx *ctx, int ref, const int *nbr_ids, int n_nbr,
 int amvs_plane_sweep_device(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *nbr_ids,
                             int n_nbr, const float *depths, int D, int patch_size,
                             float thresh, void *depth_dev, void *conf_dev);
+
+/* The reconstruct loop of DenseStereoReconstructor (dense_stereo.py:105-130) as ONE batched sweep
+ * whose maps stay in the context: [n_ref][H][W] depth and vote count.  amvs_fetch_sweep_maps copies
+ * maps first .. first+count-1 to the host (tests; the multi-rank gather).                        */
+int amvs_plane_sweep_batch(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
+                           const float *depths, int D, int patch_size, float thresh);
+int amvs_fetch_sweep_maps(amvs_ctx *ctx, int first, int count, float *depth_out, float *conf_out);
+
+/* DenseStereoReconstructor._backproject (dense_stereo.py:407-437) for n_maps reference views at once,
+ * in float64 and in the reference's order (view by view, row-major): pixels with confidence >=
+ * min_confidence and depth > 0 -> world points + RGB colours, kept on the device (amvs_fetch_cloud).
+ * maps_where: 0 = depth / conf are host arrays, 1 = device pointers, 2 = the resident maps of the last
+ * amvs_plane_sweep_batch (depth / conf ignored).  per_map_counts (optional, n_maps) receives the points
+ * of every view -- the numbers of the reference's progress lines (:129).                           */
+int amvs_stereo_backproject(amvs_ctx *ctx, int n_maps, const void *depth, const void *conf, int maps_where,
+                            const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
+                            float min_confidence, int64_t *per_map_counts, int64_t *total);
+/* amvs_knn_mean_distance on the context's resident cloud (the result of amvs_stereo_backproject /
+ * amvs_fuse_filter): the statistic of _filter_outliers without a host round trip of the points.     */
+int amvs_cloud_knn_mean_distance(amvs_ctx *ctx, int k, double *mean_out);
+/* DenseStereoReconstructor._voxel_down_sample (dense_stereo.py:475-492) of the resident cloud, after an
+ * optional keep mask (one byte per point: the outlier filter's selection, computed by the caller as
+ * the reference does with numpy): first point of every voxel in key order.  The cloud is replaced.  */
+int amvs_cloud_voxel_downsample(amvs_ctx *ctx, const uint8_t *keep_mask, double voxel_size, int64_t *count);
+/* 1 if amvs_knn_mean_distance is compiled for this neighbour count.                                */
+int amvs_knn_supported(int k);
 
 /* The k-nearest-neighbour statistic of DenseStereoReconstructor._filter_outliers
  * (dense_stereo.py:456-460: NearestNeighbors(n_neighbors=k).fit(p).kneighbors(p), then

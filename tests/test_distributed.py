@@ -42,7 +42,8 @@ def _reconstruct(scene, world_tag, use_engine=False, mode="exact"):
     import amvs
     from amvs.core.mvs_patchmatch import PatchMatchMVS
     pm = PatchMatchMVS(amvs.Camera(K=scene.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7,
-                       num_iterations=1, num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0, mode=mode)
+                       num_iterations=1, num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0, mode=mode,
+                       device_prep=use_engine)
     if not use_engine:
         backend = _oracle_backend(scene, 7, 1, 2, 5, mode)
         pm._ensure_engine = lambda images, poses, indices: setattr(pm, "_slot", {i: i for i in indices})
@@ -157,6 +158,50 @@ def test_reconstruct_two_ranks_rccl_matches_single_process(scene_a):
     for rank, pts, cols in _run_two_ranks(True, "fast", backend="nccl"):
         assert np.array_equal(pts, single_pts), f"rank {rank} cloud differs from the single-process cloud"
         assert np.array_equal(cols, single_cols)
+
+
+def _stereo_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _stereo_reconstruct())
+    finally:
+        dist.destroy_process_group()
+
+
+def _stereo_reconstruct():
+    from conftest import GoldenScene
+    from amvs.core.dense_stereo import DenseStereoReconstructor
+    import amvs
+    sc = GoldenScene("scene_d")
+    rec = DenseStereoReconstructor(amvs.Camera(K=sc.K.copy(), dist=np.zeros(5)), scale=1.0, num_depths=24, patch_size=5,
+                                   min_views=2, device=0)
+    return rec.reconstruct([{"image": c} for c in sc.colors], sc.poses(), max_pairs=30)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_stereo_reconstruct_two_ranks_match_single_process():
+    """DenseStereoReconstructor.reconstruct with the reference views sharded over two ranks (gloo,
+    both on cuda:0; 7 views -> 4 + 3) returns the single-process cloud on every rank."""
+    import torch.multiprocessing as mp
+    single_p, single_c = _stereo_reconstruct()
+    assert len(single_p) > 100
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stereo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, pts, cols in results:
+        assert np.array_equal(pts, single_p) and np.array_equal(cols, single_c), f"rank {rank}"
 
 
 def test_engine_cache_follows_the_poses(monkeypatch, scene_a):

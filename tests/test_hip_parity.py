@@ -530,6 +530,128 @@ def test_stereo_reconstruct_device_filter_equals_sklearn_filter(amvs_mod):
     assert np.array_equal(p_dev, p_host) and np.array_equal(c_dev, c_host)
 
 
+@pytest.mark.parametrize("scale", [1.0, 0.5, 0.25, 0.3, 0.6])
+def test_device_image_preparation_equals_host_restatement(amvs_mod, scale):
+    """amvs_set_view_bgr8 (upload the 8-bit BGR image, cv.resize + cvtColor arithmetic on the GPU) against
+    core/imageprep.py: identical resized colour image, identical gray map (checked through the box
+    statistics and a cost evaluation of views prepared either way)."""
+    from amvs.core.imageprep import prepare_view
+    from amvs.synthetic import make_scene
+    sc = make_scene(4, 90, 130, seed=31)
+    rng = np.random.default_rng(5)
+    imgs = [np.clip(c.astype(np.int16) + rng.integers(-20, 21, c.shape), 0, 255).astype(np.uint8) for c in sc.colors]
+    prep = [prepare_view(im, scale) for im in imgs]
+    H, W = prep[0]["shape"]
+    K = sc.camera.K.copy()
+    K[:2] *= scale
+    K = K.astype(np.float32)
+    with amvs_mod.Engine(H, W, 4, K) as dev, amvs_mod.Engine(H, W, 4, K) as host:
+        for i in range(4):
+            color = dev.set_view_bgr8(i, imgs[i], sc.poses[i].R, sc.poses[i].t)
+            assert np.array_equal(color, prep[i]["color"]), f"view {i}: resized colour image differs"
+            host.set_view(i, prep[i]["gray"], sc.poses[i].R, sc.poses[i].t)
+        assert dev.sampling_mode() == host.sampling_mode() == "u8-pairs"
+        for v in (0, 3):
+            md, vd = dev.box_stats(v, 5)
+            mh, vh = host.box_stats(v, 5)
+            _eq(md, mh, f"scale {scale} view {v} mean")
+            _eq(vd, vh, f"scale {scale} view {v} variance")
+        d = np.full((H, W), 5.0, np.float32)
+        _eq(dev.eval_cost(1, [0, 2, 3], 5, d), host.eval_cost(1, [0, 2, 3], 5, d), f"scale {scale} cost")
+
+
+def test_reconstruct_device_prep_equals_host_prep(amvs_mod):
+    """PatchMatchMVS.reconstruct and DenseStereoReconstructor.reconstruct at the CLI's scale 0.25 with the
+    images prepared on the GPU and on the host: the same cloud."""
+    from amvs.core.dense_stereo import DenseStereoReconstructor
+    from amvs.core.mvs_patchmatch import PatchMatchMVS
+    from amvs.synthetic import make_scene
+    sc = make_scene(5, 288, 384, seed=8)
+    images = [{"image": c} for c in sc.colors]
+    clouds = []
+    for device_prep in (True, False):
+        pm = PatchMatchMVS(sc.camera, scale=0.25, patch_size=5, num_iterations=2, num_samples=2, min_views=2, seed=3,
+                           device_prep=device_prep)
+        pm._estimate_depth_range = lambda poses, sparse: None
+        pm.depth_min, pm.depth_max = sc.depth_min, sc.depth_max
+        clouds.append(pm.reconstruct(images, dict(sc.poses)))
+    assert len(clouds[0][0]) > 0
+    assert np.array_equal(clouds[0][0], clouds[1][0]) and np.array_equal(clouds[0][1], clouds[1][1])
+    st = []
+    for device_prep in (True, False):
+        rec = DenseStereoReconstructor(sc.camera, scale=0.25, num_depths=16, min_views=2, device_prep=device_prep)
+        st.append(rec.reconstruct(images, dict(sc.poses), max_pairs=30))
+    assert len(st[0][0]) > 0
+    assert np.array_equal(st[0][0], st[1][0]) and np.array_equal(st[0][1], st[1][1])
+
+
+def test_stereo_post_steps_on_device_match_reference_golden(scene_c):
+    """Device back-projection, neighbour statistic and voxel down-sampling of the stereo path against
+    the clouds the REFERENCE produced (g12 from g11's maps and from the ground-truth depth):
+    bit-identical points and colours."""
+    pytest.importorskip("sklearn.neighbors")
+    g11, g12 = load_golden("g11_plane_sweep"), load_golden("g12_stereo_post")
+    ref = int(g11["ref"])
+    K_inv = np.linalg.inv(scene_c.K)
+    pose = [(scene_c.R[ref], scene_c.t[ref])]
+    cols = scene_c.colors[ref][None]
+    eng = scene_c.engine()
+    try:
+        # _backproject of the reference's own plane-sweep maps
+        counts, total, pts, rgb = eng.stereo_backproject(cols, K_inv, pose, 2.5, depth=g11["depth_map"][None],
+                                                         conf=g11["confidence"][None], fetch=True)
+        assert counts == [total] and total == len(g12["bp_points"])
+        assert np.array_equal(pts, g12["bp_points"]) and np.array_equal(rgb, g12["bp_colors"])
+        # ground-truth depth, every pixel confident: back-projection, voxel grid, outlier statistic
+        conf4 = np.full((1, scene_c.H, scene_c.W), 4.0, np.float32)
+        counts, total, pts, rgb = eng.stereo_backproject(cols, K_inv, pose, 2.5, depth=scene_c.gt_depth[ref][None],
+                                                         conf=conf4, fetch=True)
+        assert np.array_equal(pts, g12["gt_points"]) and np.array_equal(rgb, g12["gt_colors"])
+        mean_d = eng.cloud_knn_mean_distance(total, 20)
+        keep = mean_d < np.mean(mean_d) + 2.0 * np.std(mean_d)
+        assert np.array_equal(pts[keep], g12["out_points"]) and np.array_equal(rgb[keep], g12["out_colors"])
+        m = eng.cloud_voxel_downsample(0.02)
+        vp, vc = eng.fetch_cloud(m)
+        assert np.array_equal(vp, g12["vox_points"]) and np.array_equal(vc, g12["vox_colors"])
+        # mask + voxel grid in one call == numpy on the masked cloud
+        from amvs.core.dense_stereo import DenseStereoReconstructor
+        eng.stereo_backproject(cols, K_inv, pose, 2.5, depth=scene_c.gt_depth[ref][None], conf=conf4)
+        m = eng.cloud_voxel_downsample(0.02, keep)
+        got_p, got_c = eng.fetch_cloud(m)
+        rec = DenseStereoReconstructor.__new__(DenseStereoReconstructor)
+        want_p, want_c = rec._voxel_down_sample(pts[keep], rgb[keep], 0.02)
+        assert np.array_equal(got_p, want_p) and np.array_equal(got_c, want_c)
+    finally:
+        eng.close()
+
+
+def test_plane_sweep_batch_keeps_maps_resident(scene_d):
+    """amvs_plane_sweep_batch == per-view amvs_plane_sweep, and the resident maps back-project to the
+    same cloud as the host copies (per-view counts included)."""
+    g = load_golden("g16_plane_sweep_s6")
+    depths = g["depths"].astype(np.float32)
+    refs = [3, 1, 5]
+    nbrs = [[i for i in range(scene_d.n) if i != r][:6] for r in refs]
+    K_inv = np.linalg.inv(scene_d.K)
+    eng = scene_d.engine("fast")
+    try:
+        singles = [eng.plane_sweep(r, nb, depths, 5, 0.8) for r, nb in zip(refs, nbrs)]
+        eng.plane_sweep_batch(refs, nbrs, depths, 5, 0.8)
+        d, c = eng.fetch_sweep_maps(0, 3)
+        for i in range(3):
+            _eq(d[i], singles[i][0], f"batch view {i} depth")
+            _eq(c[i], singles[i][1], f"batch view {i} confidence")
+        cols = np.stack([scene_d.colors[r] for r in refs])
+        poses = [(scene_d.R[r], scene_d.t[r]) for r in refs]
+        counts_r, total_r, p_r, c_r = eng.stereo_backproject(cols, K_inv, poses, 1.5, fetch=True)      # resident maps
+        counts_h, total_h, p_h, c_h = eng.stereo_backproject(cols, K_inv, poses, 1.5, depth=d, conf=c, fetch=True)
+        assert counts_r == counts_h and total_r == total_h == sum(counts_r) and total_r > 100
+        assert counts_r == [int(((c[i] >= 1.5) & (d[i] > 0)).sum()) for i in range(3)]
+        assert np.array_equal(p_r, p_h) and np.array_equal(c_r, c_h)
+    finally:
+        eng.close()
+
+
 def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
     d = scene_a.gt_depth[2]

@@ -151,16 +151,36 @@ def test_prepare_view_identity_scale_and_gray_formula():
     out = prepare_view(img, 1.0)
     assert out["shape"] == (12, 16) and np.array_equal(out["color"], img)
     b, g, r = (img[..., i].astype(np.int64) for i in range(3))
-    gray8 = (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14
+    gray8 = (b * 3735 + g * 19235 + r * 9798 + 16384) >> 15       # OpenCV >= 4.x RGB2Gray<uchar>
     assert np.array_equal(out["gray"], gray8.astype(np.float32) / np.float32(255.0))
     half = prepare_view(img, 0.5)
     assert half["shape"] == (6, 8) and half["gray"].dtype == np.float32
+    # an exact 2x reduction equals the 2x2 area average cv.resize routes it to
+    a = img.astype(np.int64)
+    area = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(half["color"], area)
+    # cv.resize's fixed-point linear interpolation, one destination pixel by hand (scale 0.3: 12x16 -> 3x4)
+    small = prepare_view(img, 0.3)["color"]
+    assert small.shape == (3, 4, 3)
+
+    def taps(d, n_dst, n_src):
+        f = np.float32((d + 0.5) * (1.0 / (n_dst / n_src)) - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        return s, int(np.rint((np.float32(1) - f) * np.float32(2048))), int(np.rint(f * np.float32(2048)))
+    for dy, dx in ((0, 0), (1, 2), (2, 3)):
+        sx, a0, a1 = taps(dx, 4, 16)
+        sy, b0, b1 = taps(dy, 3, 12)
+        for c in range(3):
+            d0 = int(img[sy, sx, c]) * a0 + int(img[sy, sx + 1, c]) * a1
+            d1 = int(img[sy + 1, sx, c]) * a0 + int(img[sy + 1, sx + 1, c]) * a1
+            assert small[dy, dx, c] == ((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2)
     # all 2^24 colours through the 32-bit gray formula, and the thread pool keeps the order
     from amvs.core.imageprep import prepare_views
     cube = np.stack(np.meshgrid(*[np.arange(256, dtype=np.uint8)] * 3, indexing="ij"), axis=-1).reshape(4096, 4096, 3)
     b, g, r = (cube[..., i].astype(np.int64) for i in range(3))
     assert np.array_equal(prepare_view(cube, 1.0)["gray"],
-                          (((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.float32) / np.float32(255.0)))
+                          (((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.float32) / np.float32(255.0)))
     imgs = [rng.integers(0, 256, (10, 14, 3), dtype=np.uint8) for _ in range(9)]
     pooled, serial = prepare_views(imgs, 0.5), [prepare_view(im, 0.5) for im in imgs]
     assert all(np.array_equal(p["gray"], q["gray"]) and np.array_equal(p["color"], q["color"])

@@ -29,7 +29,7 @@ def timed(cls, name):
     setattr(cls, name, wrap)
 
 
-for name in ("_prepare_images", "_compute_depth_map_gpu", "_backproject", "_filter_outliers", "_voxel_down_sample"):
+for name in ("_prepare_images", "_prepare_images_device", "_sweep_and_backproject", "_filter_and_downsample_device"):
     timed(ds.DenseStereoReconstructor, name)
 for rep in range(2):
     marks.clear()
