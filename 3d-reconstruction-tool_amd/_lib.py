@@ -98,6 +98,24 @@ class AmvsError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  libamvs.so links /opt/rocm's libamdhip64.so.7; a PyTorch-ROCm
+    wheel bundles its own copy under the same SONAME, so whichever is loaded first serves both -- and
+    PyTorch cannot see the GPU ("No HIP GPUs are available") once the system copy got in first.  When
+    torch is installed its copy is therefore loaded first, whatever the import order (torch is located
+    without importing it).  Without torch the system runtime is used as linked."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001  (best effort: the linked runtime still works on its own)
+        pass
+
+
 def load():
     """Load libamvs.so and bind every declared entry point (raises if absent)."""
     global _lib
@@ -106,6 +124,7 @@ def load():
             raise AmvsError(
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                 "(or `make -C 3d-reconstruction-tool_amd/csrc`). There is no CPU fallback.")
+        _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError if a declared symbol is missing

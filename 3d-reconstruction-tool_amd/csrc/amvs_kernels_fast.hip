@@ -550,21 +550,34 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
             const float m1 = mv1.x, v1 = mv1.y;
             uint32_t votes = 0u;
-            auto vote_stage = [&](auto lean, bool &ok) {
-                constexpr bool LEAN = decltype(lean)::value;
-                votes = 0u;
+            if (a.thresh > 0.0f) {
+                // ncc > thresh (dense_stereo.py:303) without square root and division:
+                // cov / sqrt(x) > t  <=>  cov > 0, x >= 0 (a negative x is the reference's NaN) and cov^2 > t^2 x
+                const float t2 = a.thresh * a.thresh;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
                     const float mean2 = bvs[s] * C1;
                     const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
                     const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
-                    const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
-                    const float ncc = cov * rcp_t<LEAN>(den, ok);
-                    if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+                    const float x = v1 * var2 + 1e-8f;
+                    const bool vote = (cov > 0.0f) & (x >= 0.0f) & (cov * cov > t2 * x) & (((okc >> s) & 1u) != 0u);
+                    votes += vote ? 1u : 0u;
                 }
-            };
-            {
+            } else {
+                auto vote_stage = [&](auto lean, bool &ok) {
+                    constexpr bool LEAN = decltype(lean)::value;
+                    votes = 0u;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
+                        const float mean2 = bvs[s] * C1;
+                        const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
+                        const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
+                        const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
+                        const float ncc = cov * rcp_t<LEAN>(den, ok);
+                        if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
+                    }
+                };
                 bool ok = true;
                 vote_stage(std::true_type{}, ok);
                 if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);

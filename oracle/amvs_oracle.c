@@ -387,7 +387,7 @@ static inline float fast_c2(int k) { return (float)(1.0 / ((double)(k * k) * 650
  * units; the window sums keep the exact mode's order, the epilogue drops the Markstein
  * quotient refinement (one multiply by the reciprocal). */
 static void ncc_map_fast(const float *img1c, const float *m1, const float *v1,
-                         const float *img2, int H, int W, int k, int variant,
+                         const float *img2, int H, int W, int k, int variant, float thresh2,
                          float *tmp, float *b_v, float *b_vv, float *b_rv, float *out)
 {
     const float C1 = fast_c1(k), C2 = fast_c2(k);
@@ -402,9 +402,15 @@ static void ncc_map_fast(const float *img1c, const float *m1, const float *v1,
         if (variant == 0) {
             float den = sqrtf(v1[i] * var2) + 1e-8f;
             out[i] = 1.0f - cov * (1.0f / den);
-        } else {
+        } else if (variant == 1) {
             float den = sqrtf(v1[i] * var2 + 1e-8f);
             out[i] = cov * (1.0f / den);
+        } else {
+            /* variant 2: the plane sweep's vote  ncc > thresh  (dense_stereo.py:303) for thresh > 0 without
+             * the square root and the division:  cov / sqrt(x) > t  <=>  cov > 0, x >= 0 (a negative x is
+             * the reference's NaN: no vote) and cov^2 > t^2 x.  out = 1 where the vote is cast. */
+            float x = v1[i] * var2 + 1e-8f;
+            out[i] = (cov > 0.0f && x >= 0.0f && cov * cov > thresh2 * x) ? 1.0f : 0.0f;
         }
     }
 }
@@ -602,7 +608,7 @@ static void ctx_ncc(orc_ctx_t *c, const float *sampled, int variant, float *out)
 {
     const int H = c->cam.H, W = c->cam.W;
     if (c->mode)
-        ncc_map_fast(c->ref_codef, c->m1f, c->v1f, sampled, H, W, c->k, variant, c->tmp, c->bv, c->bvv, c->brv, out);
+        ncc_map_fast(c->ref_codef, c->m1f, c->v1f, sampled, H, W, c->k, variant, 0.0f, c->tmp, c->bv, c->bvv, c->brv, out);
     else
         ncc_map(c->ref, c->mean1, c->var1, sampled, H, W, c->k, variant, c->tmp, c->bv, c->bvv, c->brv, out);
 }
@@ -826,6 +832,15 @@ ORC_API void orc_plane_sweep(orc_ctx_t *c, const float *depths, int D, float thr
         for (size_t i = 0; i < n; ++i) { dmap[i] = depths[d]; votes[i] = 0.0f; }
         for (int s = 0; s < c->S; ++s) {
             sample_source(c, s, dmap, 2, c->sampled, c->valid);
+            if (c->mode && thresh > 0.0f) {
+                /* fast mode: the vote through the squared comparison (ncc_map_fast, variant 2) */
+                ncc_map_fast(c->ref_codef, c->m1f, c->v1f, c->sampled, H, W, c->k, 2, thresh * thresh,
+                             c->tmp, c->bv, c->bvv, c->brv, c->cost_s);
+#pragma omp parallel for schedule(static)
+                for (size_t i = 0; i < n; ++i)
+                    if (c->cost_s[i] != 0.0f && c->valid[i]) votes[i] += 1.0f;
+                continue;
+            }
             ctx_ncc(c, c->sampled, 1, c->cost_s);
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < n; ++i)

@@ -221,6 +221,18 @@ def test_plane_sweep_four_and_six_neighbours(scene_c, scene_d, mode):
         _eq(d2, od, f"{name} {mode} depth (chunked)")
         _eq(conf2, oc, f"{name} {mode} confidence (chunked)")
         assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
+    # thresholds <= 0 take the division form of the vote in fast mode (the squared comparison needs t > 0)
+    g = load_golden("g16_plane_sweep_s6")
+    ref, nbrs, depths = int(g["ref"]), list(g["nbrs"]), g["depths"].astype(np.float32)
+    eng = scene_d.engine(mode)
+    try:
+        for thresh in (0.0, -0.3, 0.35):
+            d, conf = eng.plane_sweep(ref, nbrs, depths, 5, thresh)
+            od, oc = scene_d.oracle_ctx(ref, nbrs, 5, mode).plane_sweep(depths, thresh)
+            _eq(d, od, f"{mode} thresh {thresh} depth")
+            _eq(conf, oc, f"{mode} thresh {thresh} confidence")
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("shape,nviews,k,S", [((9, 11), 3, 3, 2), ((5, 70), 4, 5, 3), ((66, 7), 4, 7, 3),
