@@ -131,7 +131,15 @@ def main():
                     help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")
     ap.add_argument("--scene-views", type=int, default=32, help="views of the fixed scene for N>1 (BASELINE config 4)")
     ap.add_argument("--no-planesweep", action="store_true", help="skip the plane-sweep sub-record")
+    ap.add_argument("--fusion", action="store_true",
+                    help="fuse + filter the gathered maps inside every timed step (BASELINE config 5)")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE config 5 preset: 64 views of 3840x2160 over the ranks, fusion inside the step")
     args = ap.parse_args()
+    if args.config5:
+        args.height, args.width, args.scene_views, args.fusion, args.no_planesweep = 2160, 3840, 64, True, True
+        if args.gpus == 1:
+            args.views_per_gpu = 64
     if args.workload == "planesweep":
         print(json.dumps(run_planesweep(args, args.steps, args.warmup, not args.no_cpu_baseline)), flush=True)
         return
@@ -189,59 +197,89 @@ def main():
     params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
                             args.views_per_launch, schedule=args.schedule)
     n_loc = len(mine)
-    depth = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
-    normal = torch.empty((n_loc, H, W, 3), dtype=torch.float32, device=dev)
-    conf = torch.empty((n_loc, H, W), dtype=torch.float32, device=dev)
+    if world > 1:
+        assert n_views % world == 0, "the bench shards equal blocks: --scene-views must be a multiple of --gpus"
+    # N>1: two sets of output maps used alternately, so that the all-gather of step k (which reads the
+    # maps in place, no packed copy) can run under the sweep of step k+1
+    nbuf = 2 if world > 1 else 1
+    depth = torch.empty((nbuf, n_loc, H, W), dtype=torch.float32, device=dev)
+    normal = torch.empty((nbuf, n_loc, H, W, 3), dtype=torch.float32, device=dev)
+    conf = torch.empty((nbuf, n_loc, H, W), dtype=torch.float32, device=dev)
     refs = list(mine)
     srcs = [sources[r] for r in refs]
 
-    # N>1: the rank's views are swept in `nb` batches; the RCCL all-gather of batch b runs on its
-    # own stream while batch b+1 is swept, so only the last batch's exchange is exposed
-    nb = args.batches if args.batches > 0 else (1 if world == 1 else 2)
+    # N>1: the rank's views are swept in `nb` batches; the RCCL all-gathers of batch b (three
+    # collectives: depth, normal, confidence -- 20 B/pixel, straight from and into contiguous arrays in
+    # view order) run on their own stream while the next batch / the next step is swept, so K timed
+    # steps expose one batch's exchange once, before the closing barrier
+    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 16) else 1)
     nb = max(1, min(nb, n_loc))
     bounds = [(b * n_loc) // nb for b in range(nb + 1)]
     comm_stream = torch.cuda.Stream(device=dev)
-
-    # The exchange of a batch is also allowed to run under the NEXT step's sweeps: a step only waits
-    # for the exchanges of the step before it, and the closing fence for everything (so K timed steps
-    # expose one batch's exchange once, not K times).  The gather reads a packed copy, so the next
-    # sweep may overwrite the maps as soon as that copy has been made (comm_stream order).
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    full = [dict(d=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev),
+                 n=torch.empty((world, n_loc, 3 * H * W), dtype=torch.float32, device=gdev),
+                 c=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev)) for _ in range(nbuf)] \
+        if world > 1 else None
+    fusion_inputs = None
+    if args.fusion:
+        # config 5: the fused, filtered cloud is part of the step (on rank 0, which like every rank
+        # holds all maps after the gather)
+        fusion_inputs = (np.stack([sc.colors[r] for r in ids]), np.linalg.inv(sc.camera.K),
+                         [(sc.poses[r].R, sc.poses[r].t) for r in ids])
     in_flight = []
+    state = {"step": 0, "cloud": None, "fusion_s": 0.0}
 
     def drain(keep_last_step):
         while len(in_flight) > (1 if keep_last_step else 0):
-            for w in in_flight.pop(0)[0]:
+            for w in in_flight.pop(0):
                 w.wait()
 
+    def fuse(k):
+        t_f = time.perf_counter()
+        cols, K_inv, pose_list = fusion_inputs
+        if world == 1:
+            torch.cuda.synchronize()
+            out = eng.fuse_filter(None, None, cols, K_inv, pose_list, 3, True,
+                                  device_ptrs=(depth[k].data_ptr(), conf[k].data_ptr(), n_loc))
+        elif backend == "nccl":
+            torch.cuda.synchronize()
+            out = eng.fuse_filter(None, None, cols, K_inv, pose_list, 3, True,
+                                  device_ptrs=(full[k]["d"].data_ptr(), full[k]["c"].data_ptr(), n_views))
+        else:
+            out = eng.fuse_filter(full[k]["d"].numpy().reshape(n_views, H, W), full[k]["c"].numpy().reshape(n_views, H, W),
+                                  cols, K_inv, pose_list, 3, True)
+        state["cloud"] = out
+        state["fusion_s"] += time.perf_counter() - t_f
+
     def step():
-        works, parts = [], []
+        k = state["step"] % nbuf
+        state["step"] += 1
+        works = []
         for b in range(nb):
             lo, hi = bounds[b], bounds[b + 1]
-            if world > 1:
-                stream.wait_stream(comm_stream)      # the previous packed copy of these rows is done
-            eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[lo:hi].data_ptr(),
-                                  normal[lo:hi].data_ptr(), conf[lo:hi].data_ptr())
+            eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[k, lo:hi].data_ptr(),
+                                  normal[k, lo:hi].data_ptr(), conf[k, lo:hi].data_ptr())
             if world > 1:
                 done = torch.cuda.Event()
                 done.record(stream)
                 with torch.cuda.stream(comm_stream):
                     comm_stream.wait_event(done)
-                    packed = torch.cat([depth[lo:hi].reshape(hi - lo, -1), normal[lo:hi].reshape(hi - lo, -1),
-                                        conf[lo:hi].reshape(hi - lo, -1)], dim=1)
-                    if backend != "nccl":
-                        comm_stream.synchronize()
-                        packed = packed.cpu()
-                    # every rank contributes the same batch bounds: gather (hi-lo) rows per rank
-                    recv = torch.empty((world * (hi - lo), 5 * H * W), dtype=torch.float32, device=packed.device)
-                    works.append(dist.all_gather_into_tensor(recv, packed.contiguous(), async_op=True))
-                    parts.append((lo, hi, recv, packed))
+                    for name, src_t in (("d", depth[k, lo:hi]), ("n", normal[k, lo:hi]), ("c", conf[k, lo:hi])):
+                        inp = src_t.reshape(hi - lo, -1)
+                        if backend != "nccl":
+                            comm_stream.synchronize()
+                            inp = inp.cpu()
+                        outs = [full[k][name][r, lo:hi] for r in range(world)]
+                        works.append(dist.all_gather(outs, inp, async_op=True))
         eng.sync()
         if world > 1:
-            in_flight.append((works, parts))
-            drain(keep_last_step=True)
-            gathered[0] = parts
-
-    gathered = [None]
+            in_flight.append(works)
+            # the buffers of this step are rewritten two steps from now: the step before this one must
+            # be through; with the fusion inside the step, this step's own exchange as well
+            drain(keep_last_step=not args.fusion)
+        if args.fusion and rank == 0:
+            fuse(k)
 
     def fence():
         drain(keep_last_step=False)
@@ -255,6 +293,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    state["fusion_s"] = 0.0
     t0 = time.perf_counter()
     sweep_ms = conf_ms = 0.0
     launches = 0
@@ -266,20 +305,19 @@ def main():
         launches += t["sweep_launches"] * nb
     fence()
     elapsed = time.perf_counter() - t0
+    k_last = (state["step"] - 1) % nbuf
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # every rank must now hold every view's maps: its own rows are checked bit for bit, and the
-        # rows of the other ranks must be populated
-        assert gathered[0] is not None and len(gathered[0]) == nb
-        for lo, hi, recv, _ in gathered[0]:
-            assert tuple(recv.shape) == (world * (hi - lo), 5 * H * W)
-            own = recv[rank * (hi - lo): (rank + 1) * (hi - lo)].to(dev)
-            assert torch.equal(own[:, : H * W], depth[lo:hi].reshape(hi - lo, -1)), "all-gather: own depth rows differ"
-            assert torch.equal(own[:, 4 * H * W:], conf[lo:hi].reshape(hi - lo, -1)), "all-gather: own confidence rows differ"
-            other = recv[((rank + 1) % world) * (hi - lo)].to(dev)
-            assert float(other[: H * W].min()) >= float(np.float32(sc.depth_min)) - 1e-3, "all-gather: peer rows empty"
+        # every rank must now hold every view's maps, in view order: its own block is checked bit for
+        # bit and the neighbour's block must be populated
+        fd, fc = full[k_last]["d"], full[k_last]["c"]
+        assert torch.equal(fd[rank].to(dev), depth[k_last].reshape(n_loc, -1)), "all-gather: own depth rows differ"
+        assert torch.equal(fc[rank].to(dev), conf[k_last].reshape(n_loc, -1)), "all-gather: own confidence rows differ"
+        other = fd[(rank + 1) % world]
+        assert float(other.min()) >= float(np.float32(sc.depth_min)) - 1e-3, "all-gather: peer rows empty"
+        assert float(full[k_last]["n"][(rank + 1) % world].abs().max()) > 0.0, "all-gather: peer normals empty"
 
     n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
@@ -305,9 +343,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 3: {n_views}-view {W}x{H} PatchMatch MVS, " if world == 1 else
-                                    f"BASELINE config 4: {n_views}-view {W}x{H} PatchMatch MVS scene, {vpg} views per GPU, "
-                                    f"RCCL all-gather of the maps, ") +
+            "config": {"workload": ((f"BASELINE config 5: {n_views}-view {W}x{H} PatchMatch MVS + fusion, {vpg} views per GPU, "
+                                     if args.config5 else
+                                     f"BASELINE config 3: {n_views}-view {W}x{H} PatchMatch MVS, ") if world == 1 else
+                                    (f"BASELINE config {5 if args.config5 else 4}: {n_views}-view {W}x{H} PatchMatch MVS scene, "
+                                     f"{vpg} views per GPU, RCCL all-gather of the maps"
+                                     + (", fusion inside the step, " if args.fusion else ", "))) +
                                    f"{args.iters} iters x (2+{args.samples}) hypotheses, {args.patch}x{args.patch} NCC, "
                                    f"{S} sources, {args.mode} arithmetic",
                        "views_per_gpu": vpg, "scene_views": n_views, "width": W, "height": H, "patch": args.patch,
@@ -326,14 +367,19 @@ def main():
         # "dense points/s": fuse + filter the maps of the last step (untimed above) on the device
         # (amvs_fuse_filter = mvs_patchmatch.py:536-588, bit-identical to the NumPy path) and relate
         # the cloud to sweep + fusion time
-        if world == 1:
+        if args.fusion and state["cloud"] is not None:
+            pts, cols, raw = state["cloud"]
+            out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": True,
+                                   "points_per_s": round(len(pts) / (elapsed / args.steps), 1),
+                                   "device_fusion_s": round(state["fusion_s"] / args.steps, 4)}
+        elif world == 1:
             torch.cuda.synchronize()
             t_f = time.perf_counter()
             pts, cols, raw = eng.fuse_filter(None, None, np.stack([sc.colors[r] for r in refs]),
                                              np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in refs],
-                                             3, True, device_ptrs=(depth.data_ptr(), conf.data_ptr(), n_loc))
+                                             3, True, device_ptrs=(depth[k_last].data_ptr(), conf[k_last].data_ptr(), n_loc))
             t_f = time.perf_counter() - t_f
-            out["dense_points"] = {"raw": raw, "final": int(len(pts)),
+            out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": False,
                                    "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),
                                    "device_fusion_s": round(t_f, 4)}
         if world == 1 and not args.no_cpu_baseline:
@@ -343,7 +389,7 @@ def main():
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
 
     eng.close()
-    del eng, depth, normal, conf
+    del eng, depth, normal, conf, full
     if rank == 0:
         if world == 1 and not args.no_planesweep:
             # BASELINE config 2 beside it: a few steps (about 10 ms each) and a short CPU leg
