@@ -27,6 +27,13 @@ class PmParams(C.Structure):
                 ("schedule", C.c_int32)]
 
 
+class XpmParams(C.Structure):
+    _fields_ = [("patch_size", C.c_int32), ("window_stride", C.c_int32), ("num_refine", C.c_int32),
+                ("view_propagation", C.c_int32), ("depth_min", C.c_float), ("depth_max", C.c_float),
+                ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float),
+                ("consistency_px", C.c_float), ("consistency_rel", C.c_float)]
+
+
 class Timing(C.Structure):
     _fields_ = [("init_ms", C.c_double), ("sweep_ms", C.c_double), ("confidence_ms", C.c_double),
                 ("sweep_launches", C.c_int64), ("pixel_hypotheses", C.c_int64)]
@@ -69,6 +76,12 @@ SIGNATURES = {
     "amvs_cloud_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "amvs_cloud_voxel_downsample": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_double, C.POINTER(C.c_int64)]),
     "amvs_knn_supported": (C.c_int, [C.c_int]),
+    "amvs_xpm_init": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_uint64,
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amvs_xpm_iterate": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_int, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amvs_xpm_consistency": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_eval_cost": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),
     "amvs_sample_sources": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f32p, f32p,
                                       C.POINTER(C.c_uint8)]),

@@ -77,7 +77,7 @@ class PatchMatchMVS:
                  depth_min: float = 0.1, depth_max: float = 100.0, *,
                  seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
                  process_group=None, device_fusion: bool = True, mode: str = "fast",
-                 device_prep: bool = True):
+                 device_prep: bool = True, extended: bool = False):
         self.camera = camera
         self.scale = scale
         self.patch_size = patch_size
@@ -91,6 +91,11 @@ class PatchMatchMVS:
         self.process_group = process_group
         self.device_fusion = device_fusion
         self.device_prep = device_prep           # resize / gray conversion on the GPU (amvs_set_view_bgr8)
+        # Extended mode (off by default, NO reference counterpart -- the reference's docstring names view
+        # propagation and plane normals, :1-13, its code implements neither): slanted-plane cost,
+        # red-black propagation, view propagation fed by the other views' maps (all-gathered between
+        # iterations on several GPUs), geometric-consistency confidence.  Judged against ground truth.
+        self.extended = extended
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         self.mode = mode
@@ -135,6 +140,19 @@ class PatchMatchMVS:
                 print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: skipped (not enough neighbors)")
                 continue
             jobs.append((ref_idx, src))
+
+        if self.extended and jobs:
+            torch = _torch_cuda()
+            if torch is None:
+                raise RuntimeError("the extended mode keeps its state in device tensors: PyTorch-ROCm with a GPU is required")
+            resident = self._sweep_extended(torch, jobs, proc_images, poses, cam_indices)
+            print("\nFusing depth maps...")
+            points, colors, raw = self._fuse_filter_resident(resident, proc_images, poses)
+            print(f"  Raw points: {raw:,}")
+            if raw > 0:
+                print(f"  After filtering: {len(points):,}")
+            print(f"\nPatchMatch MVS completed in {time.time() - t0:.1f}s")
+            return points, colors
 
         torch = _torch_cuda() if self.device_fusion else None
         if torch is not None and jobs:
@@ -368,6 +386,76 @@ class PatchMatchMVS:
             order = mine
         return _ResidentMaps(ref_ids=[jobs[j][0] for j in order], depth=depth, normal=normal,
                              confidence=conf, shape=(H, W))
+
+    def _sweep_extended(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
+        """The extended mode (csrc/amvs_extended.hip): the state of ALL views lives in device tensors;
+        this rank iterates its shard of the reference views, and after every iteration the ranks
+        all-gather the depth / normal / cost maps -- the exchange `north_star` places between the
+        propagation sweeps, feeding the next iteration's view propagation and the final geometric
+        consistency.  Confidence = number of geometrically consistent source views."""
+        n_cams = len(cam_indices)
+        rank, world = _parallel.rank_world(self.process_group)
+        mine = _parallel.shard(len(jobs), rank, world)
+        eng = self._ensure_engine(proc_images, poses, cam_indices)
+        H, W = proc_images[cam_indices[0]]["shape"]
+        hw = H * W
+        dev = torch.device("cuda", self.device_id)
+        n_views = len(cam_indices)
+        depth = torch.zeros((n_views, hw), dtype=torch.float32, device=dev)
+        normal = torch.zeros((n_views, 3 * hw), dtype=torch.float32, device=dev)
+        cost = torch.full((n_views, hw), float("inf"), dtype=torch.float32, device=dev)
+        params = _engine.make_xpm_params(self.patch_size, self.depth_min, self.depth_max,
+                                         window_stride=2 if self.patch_size >= 7 else 1, num_refine=2)
+        groups = {}
+        for j in mine:                                     # one call has one source count
+            groups.setdefault(len(jobs[j][1]), []).append(j)
+        calls = [([self._slot[jobs[j][0]] for j in js], [[self._slot[s] for s in jobs[j][1]] for j in js], js)
+                 for _, js in sorted(groups.items())]
+        slots_all = torch.tensor([self._slot[jobs[j][0]] for j in range(len(jobs))], dtype=torch.long, device=dev)
+        slots_mine = torch.tensor([self._slot[jobs[j][0]] for j in mine], dtype=torch.long, device=dev)
+        direct = world > 1 and torch.distributed.get_backend(self.process_group) == "nccl"
+
+        def exchange():
+            if world == 1:
+                return
+            for t, width in ((depth, hw), (normal, 3 * hw), (cost, hw)):
+                local = t[slots_mine]
+                full = _parallel.allgather_packed(local if direct else local.cpu(), len(jobs), width, self.process_group)
+                t[slots_all] = full if direct else full.to(dev)
+
+        ptrs = (depth.data_ptr(), normal.data_ptr(), cost.data_ptr())
+        torch.cuda.synchronize(dev)
+        t1 = time.time()
+        for refs, srcs, _ in calls:
+            eng.xpm_init(refs, srcs, params, self.seed_for_stream(), *ptrs)
+        eng.sync()
+        exchange()
+        for it in range(self.num_iterations):
+            for refs, srcs, _ in calls:
+                eng.xpm_iterate(refs, srcs, params, it, self.seed_for_stream(), *ptrs)
+            eng.sync()
+            exchange()
+        conf = torch.zeros((len(jobs), hw), dtype=torch.float32, device=dev)
+        row = {j: n for n, j in enumerate(mine)}
+        conf_mine = torch.zeros((len(mine), hw), dtype=torch.float32, device=dev)
+        for refs, srcs, js in calls:
+            block = torch.empty((len(js), hw), dtype=torch.float32, device=dev)
+            eng.xpm_consistency(refs, srcs, params, *ptrs, block.data_ptr())
+            eng.sync()
+            for n, j in enumerate(js):
+                conf_mine[row[j]] = block[n]
+        if world > 1:
+            full = _parallel.allgather_packed(conf_mine if direct else conf_mine.cpu(), len(jobs), hw, self.process_group)
+            conf = full if direct else full.to(dev)
+        else:
+            conf = conf_mine
+        per_view = (time.time() - t1) / max(len(mine), 1)
+        valid = (conf >= self.min_views).sum(dim=1).tolist()
+        for j in range(len(jobs)):
+            ref_idx = jobs[j][0]
+            print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: {int(valid[j]):,} valid pixels ({per_view:.1f}s)")
+        return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(len(jobs))], depth=depth[slots_all].contiguous(),
+                             normal=normal[slots_all].contiguous(), confidence=conf.contiguous(), shape=(H, W))
 
     # ------------------------------------------------------------ fusion / filter --
     def _fuse_filter_resident(self, maps: "_ResidentMaps", images: Dict, poses: Dict[int, CameraPose]):

@@ -62,6 +62,9 @@ struct amvs_ctx {
     int cap_planes = 0;
     unsigned *d_keys = nullptr;          // plane-sweep running best, [slot][H*W]
     int cap_keys = 0;
+    float *d_xcand_d = nullptr, *d_xcand_n = nullptr;           // extended mode: view-propagation candidates
+    int *d_xsrc = nullptr;
+    int cap_x = 0, cap_xsrc = 0;
     float *d_sweep_depth = nullptr, *d_sweep_conf = nullptr;   // maps of the last amvs_plane_sweep_batch
     int cap_sweep = 0, n_sweep = 0;
     double *d_cloud_pts = nullptr;       // result of the last amvs_fuse_filter
@@ -182,7 +185,8 @@ int ensure_fast_stats(amvs_ctx *c, int patch)
 
 // `fast_patch` > 0: also fill the fast-mode records (precomposed projections, ref statistics of
 // that patch size)
-int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, int fast_patch = 0)
+int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, int fast_patch = 0,
+                bool compose_only = false)
 {
     if (n_ref <= 0 || !ref_ids || !src_ids) return fail(c, AMVS_EINVAL, "empty batch");
     const float2 *fmaps = nullptr;
@@ -217,7 +221,7 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
             j.src[s].gray = (unsigned long long)(uintptr_t)(c->d_images + (long long)v * c->stride);
             std::memcpy(j.src[s].R, c->R[v].data(), 36);
             std::memcpy(j.src[s].t, c->t[v].data(), 12);
-            if (fast_patch > 0) {
+            if (fast_patch > 0 || compose_only) {
                 amvs::fast_compose(c->K, c->R[r].data(), c->t[r].data(), c->R[v].data(), c->t[v].data(),
                                    j.fsrc[s].M, j.fsrc[s].b);
                 j.fsrc[s].pairs = j.src[s].pairs;
@@ -482,6 +486,9 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_jobs) (void)hipFree(c->d_jobs);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_xcand_d) (void)hipFree(c->d_xcand_d);
+    if (c->d_xcand_n) (void)hipFree(c->d_xcand_n);
+    if (c->d_xsrc) (void)hipFree(c->d_xsrc);
     if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
     if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
     if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
@@ -900,7 +907,10 @@ int amvs_plane_sweep_batch(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
     if (n_ref > c->cap_sweep) {
-        if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
+        if (c->d_xcand_d) (void)hipFree(c->d_xcand_d);
+    if (c->d_xcand_n) (void)hipFree(c->d_xcand_n);
+    if (c->d_xsrc) (void)hipFree(c->d_xsrc);
+    if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
         if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
         c->d_sweep_depth = c->d_sweep_conf = nullptr; c->cap_sweep = 0;
         HIPCHK(c, hipMalloc(&c->d_sweep_depth, 4 * hw * n_ref));
@@ -1006,6 +1016,95 @@ int amvs_cloud_voxel_downsample(amvs_ctx *c, const uint8_t *keep_mask, double vo
 }
 
 int amvs_knn_supported(int k) { return amvs::knn_supported(k) ? 1 : 0; }
+
+// ---- extended mode (csrc/amvs_extended.hip) ----
+static int xpm_begin(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                     void *depth_all, void *normal_all, void *cost_all, amvs::XArgs &a)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!p || !depth_all || !normal_all || !cost_all) return fail(c, AMVS_EINVAL, "NULL argument");
+    if (p->patch_size < 3 || p->patch_size > 31 || (p->patch_size & 1) == 0 || p->window_stride < 1)
+        return fail(c, AMVS_EINVAL, "extended mode: odd patch_size in 3..31 and window_stride >= 1");
+    if (n_src < 2 || n_src > AMVS_MAX_SRC) return fail(c, AMVS_EUNSUPPORTED, "n_src outside [2, 6]");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src, 0, true))) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    if (n_ref > c->cap_x) {
+        if (c->d_xcand_d) (void)hipFree(c->d_xcand_d);
+        if (c->d_xcand_n) (void)hipFree(c->d_xcand_n);
+        c->d_xcand_d = c->d_xcand_n = nullptr; c->cap_x = 0;
+        HIPCHK(c, hipMalloc(&c->d_xcand_d, 4 * hw * n_ref));
+        HIPCHK(c, hipMalloc(&c->d_xcand_n, 12 * hw * n_ref));
+        c->cap_x = n_ref;
+    }
+    if (n_ref * n_src > c->cap_xsrc) {
+        if (c->d_xsrc) (void)hipFree(c->d_xsrc);
+        c->d_xsrc = nullptr; c->cap_xsrc = 0;
+        HIPCHK(c, hipMalloc(&c->d_xsrc, sizeof(int) * n_ref * n_src));
+        c->cap_xsrc = n_ref * n_src;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_xsrc, src_ids, sizeof(int) * n_ref * n_src, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    a = amvs::XArgs{};
+    a.H = c->H; a.W = c->W; a.n_jobs = n_ref; a.n_src = n_src;
+    a.jobs = c->d_jobs; a.images = c->d_images; a.img_stride = c->stride;
+    a.depth = (float *)depth_all; a.normal = (float *)normal_all; a.cost = (float *)cost_all;
+    a.cand_d = c->d_xcand_d; a.cand_n = c->d_xcand_n; a.src_view = c->d_xsrc;
+    a.patch = p->patch_size; a.stride = p->window_stride;
+    a.depth_min = p->depth_min; a.depth_max = p->depth_max;
+    return AMVS_OK;
+}
+
+int amvs_xpm_init(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                  uint64_t seed, void *depth_all, void *normal_all, void *cost_all)
+{
+    amvs::XArgs a;
+    int rc = xpm_begin(c, n_ref, ref_ids, src_ids, n_src, p, depth_all, normal_all, cost_all, a);
+    if (rc) return rc;
+    a.seed = seed;
+    HIPCHK(c, amvs::launch_xpm_init(a, p->log_depth_scale, p->log_depth_min, c->stream));
+    return AMVS_OK;
+}
+
+int amvs_xpm_iterate(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                     int iteration, uint64_t seed, void *depth_all, void *normal_all, void *cost_all)
+{
+    amvs::XArgs a;
+    int rc = xpm_begin(c, n_ref, ref_ids, src_ids, n_src, p, depth_all, normal_all, cost_all, a);
+    if (rc) return rc;
+    if (iteration < 0) return fail(c, AMVS_EINVAL, "negative iteration");
+    a.seed = seed;
+    const double shrink = std::pow(0.5, iteration);
+    a.rel_range = (float)std::max(0.2 * shrink, 0.004);
+    a.nrm_range = (float)std::max(0.4 * shrink, 0.01);
+    a.n_refine = p->num_refine < 0 ? 0 : (p->num_refine > 6 ? 6 : p->num_refine);
+    a.with_random = iteration < 2;
+    // view propagation from a snapshot: the candidates of this iteration come from source
+    // (iteration mod n_src) of every view, read before any map is written
+    a.with_view_cand = p->view_propagation ? 1 : 0;
+    if (a.with_view_cand) {
+        a.colour = iteration % n_src;
+        HIPCHK(c, amvs::launch_xpm_view_candidates(a, c->stream));
+    }
+    for (int colour = 0; colour < 2; ++colour) {
+        a.colour = colour;
+        a.draw = (unsigned)(1 + 2 * iteration + colour);
+        HIPCHK(c, amvs::launch_xpm_sweep(a, c->stream));
+    }
+    return AMVS_OK;
+}
+
+int amvs_xpm_consistency(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                         const amvs_xpm_params *p, void *depth_all, void *normal_all, void *cost_all, void *conf_out)
+{
+    amvs::XArgs a;
+    int rc = xpm_begin(c, n_ref, ref_ids, src_ids, n_src, p, depth_all, normal_all, cost_all, a);
+    if (rc) return rc;
+    if (!conf_out) return fail(c, AMVS_EINVAL, "NULL output");
+    HIPCHK(c, amvs::launch_xpm_consistency(a, (float *)conf_out, p->consistency_px, p->consistency_rel, c->stream));
+    return AMVS_OK;
+}
 
 int amvs_eval_cost(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size,
                    const float *depth_in, float *cost_out)

@@ -133,6 +133,29 @@ hipError_t fuse_filter(const float *depth, const float *conf, const unsigned cha
                        const double *Kinv_h, const double *poses_h, float min_views, bool do_filter,
                        double **pts_out, unsigned char **rgb_out, long long counts[2], hipStream_t st);
 
+// amvs_extended.hip: the extended PatchMatch mode (slanted-plane cost, red-black schedule, view
+// propagation, geometric consistency); no reference counterpart
+struct XArgs {
+    int H, W, n_jobs, n_src;
+    const Job *jobs;
+    const float *images;          // float32 gray maps [n_views][img_stride]
+    long long img_stride;
+    float *depth, *normal, *cost; // state of ALL views: [n_views][H*W] (normal x3), indexed by Job::ref_img
+    float *cand_d, *cand_n;       // view-propagation candidates [n_jobs][H*W] (x3), indexed by Job::slot
+    const int *src_view;          // [n_jobs][n_src] view ids of the sources
+    int patch, stride;            // window side, sample stride inside it
+    float depth_min, depth_max;
+    float rel_range, nrm_range;   // refinement ranges of this iteration
+    int n_refine, with_random, colour, with_view_cand;
+    unsigned long long seed;
+    unsigned draw;
+};
+
+hipError_t launch_xpm_init(const XArgs &a, float log_scale, float log_min, hipStream_t st);
+hipError_t launch_xpm_view_candidates(const XArgs &a, hipStream_t st);
+hipError_t launch_xpm_sweep(const XArgs &a, hipStream_t st);
+hipError_t launch_xpm_consistency(const XArgs &a, float *conf_out, float max_px, float max_rel, hipStream_t st);
+
 // amvs_prep.hip: cv.resize (INTER_LINEAR, 8-bit BGR) + cvtColor(BGR2GRAY) / 255 of one view; the
 // weight tables are built on the host (amvs_capi.hip, OpenCV's float32 arithmetic)
 hipError_t launch_prep_bgr8(const unsigned char *src, int sh, int sw, int dh, int dw, const int *xofs,

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AmvsError, PmParams, Timing, f32p, i32p
+from ._lib import AmvsError, PmParams, Timing, XpmParams, f32p, i32p
 
 
 def _f32(a, shape=None):
@@ -33,6 +33,16 @@ def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max
                     int(views_per_launch), float(depth_min), float(depth_max),
                     float(np.float32(log_max - log_min)), float(np.float32(log_min)), _lib.MODES[mode],
                     _lib.SCHEDULES[schedule])
+
+
+def make_xpm_params(patch_size, depth_min, depth_max, window_stride=2, num_refine=2, view_propagation=True,
+                    consistency_px=1.0, consistency_rel=0.01):
+    """amvs_xpm_params of the extended mode (include/amvs.h)."""
+    log_min = np.log(float(depth_min))
+    log_max = np.log(float(depth_max))
+    return XpmParams(int(patch_size), int(window_stride), int(num_refine), int(bool(view_propagation)),
+                     float(depth_min), float(depth_max), float(np.float32(log_max - log_min)), float(np.float32(log_min)),
+                     float(consistency_px), float(consistency_rel))
 
 
 class Engine:
@@ -199,6 +209,25 @@ class Engine:
         c = np.empty((count, self.H, self.W), np.float32)
         self._chk(self._lib.amvs_fetch_sweep_maps(self._h, int(first), int(count), _p(d), _p(c)))
         return d, c
+
+    # -- extended mode ----------------------------------------------------------
+    def _xpm_call(self, fn, ref_ids, src_ids, params, extra, ptrs):
+        ref, refp = _ids(ref_ids)
+        src, srcp = _ids(src_ids)
+        n = ref.shape[0]
+        src = src.reshape(n, -1)
+        self._chk(fn(self._h, n, refp, srcp, src.shape[1], C.byref(params), *extra, *[C.c_void_p(p) for p in ptrs]))
+
+    def xpm_init(self, ref_ids, src_ids, params, seed, depth_ptr, normal_ptr, cost_ptr):
+        self._xpm_call(self._lib.amvs_xpm_init, ref_ids, src_ids, params, (int(seed),), (depth_ptr, normal_ptr, cost_ptr))
+
+    def xpm_iterate(self, ref_ids, src_ids, params, iteration, seed, depth_ptr, normal_ptr, cost_ptr):
+        self._xpm_call(self._lib.amvs_xpm_iterate, ref_ids, src_ids, params, (int(iteration), int(seed)),
+                       (depth_ptr, normal_ptr, cost_ptr))
+
+    def xpm_consistency(self, ref_ids, src_ids, params, depth_ptr, normal_ptr, cost_ptr, conf_ptr):
+        self._xpm_call(self._lib.amvs_xpm_consistency, ref_ids, src_ids, params, (),
+                       (depth_ptr, normal_ptr, cost_ptr, conf_ptr))
 
     # -- stereo post-steps on the device --------------------------------------
     def stereo_backproject(self, colors_bgr, K_inv64, poses, min_confidence, depth=None, conf=None, fetch=False):

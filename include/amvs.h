@@ -196,6 +196,34 @@ int amvs_fuse_filter(amvs_ctx *ctx, int n_maps, const void *depth, const void *c
                      float min_views, int do_filter, int64_t counts[2]);
 int amvs_fetch_cloud(amvs_ctx *ctx, double *points_out, uint8_t *colors_out);
 
+/* ---- extended mode: what the reference's docstring names but does not implement ----------------
+ * (mvs_patchmatch.py:1-13 lists plane hypotheses with normals and VIEW propagation; its code ignores
+ * the normal in the cost, :323-390, and has no view propagation.)  Slanted-plane homography cost,
+ * red-black in-place propagation, view propagation from a snapshot of the other views' maps, random
+ * refinement, geometric-consistency confidence.  No reference counterpart, hence no parity: judged
+ * against synthetic ground truth (tests/test_extended_mode.py); off unless a caller asks for it.
+ * State arrays are caller-owned DEVICE memory covering ALL views of the context: depth / cost
+ * [n_views][H][W], normal [n_views][H][W][3]; a call updates the rows of ref_ids and reads the others
+ * (view propagation, consistency) -- on several GPUs the caller all-gathers the rows between
+ * iterations.  conf_out of amvs_xpm_consistency is [n_ref][H][W] in ref_ids order.                */
+typedef struct {
+    int32_t patch_size;       /* odd window side, 3..31                                  */
+    int32_t window_stride;    /* sample every window_stride-th pixel of the window       */
+    int32_t num_refine;       /* perturbed hypotheses per pixel and half sweep (0..6)    */
+    int32_t view_propagation; /* 0 / 1                                                   */
+    float   depth_min, depth_max;
+    float   log_depth_scale, log_depth_min;     /* as amvs_pm_params                     */
+    float   consistency_px, consistency_rel;    /* forward-backward thresholds           */
+} amvs_xpm_params;
+int amvs_xpm_init(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                  const amvs_xpm_params *p, uint64_t seed, void *depth_all, void *normal_all, void *cost_all);
+int amvs_xpm_iterate(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                     const amvs_xpm_params *p, int iteration, uint64_t seed,
+                     void *depth_all, void *normal_all, void *cost_all);
+int amvs_xpm_consistency(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                         const amvs_xpm_params *p, void *depth_all, void *normal_all, void *cost_all,
+                         void *conf_out);
+
 /* ---- single-step entry points (parity tests drive these one reference call at a time) ---- */
 
 /* _compute_patch_cost (mvs_patchmatch.py:323-390): depth map in, averaged cost out. */
