@@ -10,7 +10,7 @@ repository root.
 from .core.camera import Camera, CameraPose, load_calibration  # noqa: F401
 
 __all__ = ["Camera", "CameraPose", "load_calibration", "PatchMatchMVS", "DepthNormalMap",
-           "DenseStereoReconstructor", "Engine"]
+           "DenseStereoReconstructor", "Engine", "AmvsError"]
 
 
 def __getattr__(name):
@@ -25,4 +25,7 @@ def __getattr__(name):
     if name == "Engine":
         from .engine import Engine
         return Engine
+    if name == "AmvsError":
+        from ._lib import AmvsError
+        return AmvsError
     raise AttributeError(name)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
 MODES = {"default": 0, "exact": 1, "fast": 2}
-SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2}
+SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2, "split": 3}
 SUPPORTED_PATCH_SIZES = (3, 5, 7, 9, 11)
 
 f32p = C.POINTER(C.c_float)
@@ -62,6 +62,7 @@ SIGNATURES = {
     "amvs_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "amvs_get_mode": (C.c_int, [C.c_void_p]),
     "amvs_set_sweep_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "amvs_set_split_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "amvs_last_tile_rows": (C.c_int, [C.c_void_p]),
     "amvs_last_views_per_launch": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,

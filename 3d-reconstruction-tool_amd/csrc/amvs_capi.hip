@@ -70,6 +70,13 @@ struct amvs_ctx {
     double *d_cloud_pts = nullptr;       // result of the last amvs_fuse_filter
     unsigned char *d_cloud_rgb = nullptr;
     long long cloud_n = 0;
+    // split schedule (amvs_pm_params.schedule == AMVS_SCHEDULE_SPLIT): sample maps, one stream per
+    // view group, the token events that serialise the sampling kernels across the groups
+    float *d_samples = nullptr;
+    size_t cap_samples = 0;
+    std::vector<hipStream_t> split_streams;  // [0] sampling kernels, [1] window kernels
+    std::vector<hipEvent_t> split_events;    // [0] fork, [1 + g] sampled(g), [9 + g] windowed(g)
+    int split_groups = 0, split_sample_rows = 0, split_sample_lds = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_tile_rows = 0, last_views_per_launch = 0;
@@ -368,6 +375,205 @@ void resolve_timing(amvs_ctx *c)
     }
 }
 
+// The sweep schedule of one PatchMatch call as a list of launches (the same for every view).
+struct SchedStep {
+    int mode, oy, ox;
+    float depth_range, normal_range;
+    unsigned draw;
+    int flip_d, flip_n;                  // buffers ping-ponged by the step (set_io)
+};
+
+std::vector<SchedStep> build_schedule(const amvs_pm_params *p)
+{
+    std::vector<SchedStep> v;
+    for (int it = 0; it < p->num_iterations; ++it) {
+        // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
+        // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
+        const int sgn = (it % 2 == 0) ? 1 : -1;
+        for (int k = 0; k < 2; ++k)
+            v.push_back(SchedStep{amvs::MODE_PROP, k == 0 ? sgn : 0, k == 0 ? 0 : sgn, 0.f, 0.f, 0u, 1, 1});
+        // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
+        const float dr = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
+        const float nr = (float)(0.5 * std::pow(0.5, it));
+        for (int s = 0; s < p->num_samples; ++s)
+            v.push_back(SchedStep{amvs::MODE_REFINE, 0, 0, dr, nr, (unsigned)(1 + it * p->num_samples + s), 1, 0});
+    }
+    return v;
+}
+
+void apply_step(amvs::StepArgs &a, const SchedStep &st)
+{
+    a.mode = st.mode; a.oy = st.oy; a.ox = st.ox;
+    if (st.mode == amvs::MODE_REFINE) { a.depth_range = st.depth_range; a.normal_range = st.normal_range; a.draw = st.draw; }
+}
+
+// One stream: the batch in groups of `vpl` views, each group through the whole schedule with the
+// fused kernel (sampling + window sums + selection in one launch).
+int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *p, uint64_t seed, int fast,
+                       const std::vector<SchedStep> &sched, void *conf_dev)
+{
+    const size_t hw = (size_t)c->H * c->W;
+    // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
+    // `vpl` views, each group through the whole schedule (see default_views_per_launch).
+    int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
+    if (vpl > n_ref) vpl = n_ref;
+    const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
+    const int TH = p->tile_rows > 0 || !band_major
+                       ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0)
+                       : pick_band_rows(c, p->patch_size, n_src, vpl, fast != 0);
+    c->last_tile_rows = TH;
+    const int n_groups = (n_ref + vpl - 1) / vpl;
+    // events: [0] start, then per group: after init, after steps, after confidence
+    while ((int)c->ev_groups.size() < 3 * n_groups) {
+        hipEvent_t ev;
+        HIPCHK(c, hipEventCreate(&ev));
+        c->ev_groups.push_back(ev);
+    }
+    c->timing_groups = n_groups;
+    int64_t launches = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
+        amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
+        a.fast = fast;
+        a.band_major = band_major;
+        a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
+        a.depth_min = p->depth_min; a.depth_max = p->depth_max;
+        a.seed = seed;
+        int cur = 0, cur_n = 0;
+        // initialisation (mvs_patchmatch.py:268-284)
+        HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
+                                    c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g], c->stream));
+        for (const SchedStep &st : sched) {
+            apply_step(a, st);
+            set_io(a, c, cur, cur_n);
+            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+            cur ^= st.flip_d; cur_n ^= st.flip_n; ++launches;
+        }
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 1], c->stream));
+        // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
+        a.mode = amvs::MODE_CONF;
+        set_io(a, c, cur, cur_n);
+        a.aux = (float *)conf_dev;
+        HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
+    }
+    c->timing.sweep_launches = launches;
+    c->last_views_per_launch = vpl;
+    return AMVS_OK;
+}
+
+// Split schedule (fast mode).  A sweep step is two kernels: the SAMPLING kernel visits every pixel
+// once -- no strip halo -- and is bound by the CU's L1 line rate for scattered gathers; the WINDOW
+// kernel streams the sample maps (coalesced) through the box sums, NCC and selection.  They stress
+// different parts of the CU, so the batch is cut into G view groups and the two kernel kinds run on
+// two streams (distinct priorities, so that they land on distinct hardware queues):
+//     sampling stream:  sample(g0,n) sample(g1,n) sample(g0,n+1) ...   (never two of them at once)
+//     window stream:    window(g,n) after sample(g,n); sample(g,n+1) after window(g,n)   (events)
+// so window(g,n) runs under the sampling of the next group.  Views are independent
+// (mvs_patchmatch.py:104-123), nothing else orders the groups.  Results are those of the fused kernel
+// bit for bit (same arithmetic, same order of every sum).
+int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *p, uint64_t seed,
+                       const std::vector<SchedStep> &sched, void *conf_dev)
+{
+    const size_t hw = (size_t)c->H * c->W;
+    constexpr int MAXG = 8;
+    int G = p->views_per_launch > 0 ? (n_ref + p->views_per_launch - 1) / p->views_per_launch
+                                    : (c->split_groups > 0 ? c->split_groups : 2);
+    if (G > n_ref) G = n_ref;
+    if (G > MAXG) G = MAXG;
+    const int vpl = (n_ref + G - 1) / G;
+    G = (n_ref + vpl - 1) / vpl;
+    const size_t need = (size_t)n_ref * n_src * hw;
+    if (need > c->cap_samples) {
+        if (c->d_samples) (void)hipFree(c->d_samples);
+        c->d_samples = nullptr; c->cap_samples = 0;
+        HIPCHK(c, hipMalloc(&c->d_samples, 4 * need));
+        c->cap_samples = need;
+    }
+    if (c->split_streams.empty()) {
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));        // lo = least urgent
+        for (int i = 0; i < 2; ++i) {
+            hipStream_t st;
+            HIPCHK(c, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, i == 0 ? lo : hi));
+            c->split_streams.push_back(st);
+        }
+    }
+    while ((int)c->split_events.size() < 1 + 2 * MAXG) {
+        hipEvent_t ev;
+        HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->split_events.push_back(ev);
+    }
+    while ((int)c->ev_groups.size() < 3) {
+        hipEvent_t ev;
+        HIPCHK(c, hipEventCreate(&ev));
+        c->ev_groups.push_back(ev);
+    }
+    c->timing_groups = 1;
+    // The window kernel gathers nothing, so its strips can be tall (vertical halo 1.09 at 64 rows);
+    // the sampling kernel has no halo at all and wants SHORT strips (the resident waves then touch
+    // fewer source rows at once).  Measured on MI355X, 16 views 1080p, k=7, S=4, 2 groups, ms per step:
+    // window rows 32 / 48 / 64 / 96: 67.4 / 67.3 / 66.5 / 68.3; sampling rows 16 / 8 / 4 / 2: 70.8 / 68.4 /
+    // 65.2-66.8 / 66.5.
+    const int TH = p->tile_rows > 0 ? p->tile_rows : (c->H < 64 ? c->H : 64);
+    c->last_tile_rows = TH;
+    const int s_TH = c->split_sample_rows > 0 ? c->split_sample_rows : 4;
+    hipStream_t s_smp = c->split_streams[0], s_win = c->split_streams[1];
+    hipEvent_t ev_fork = c->split_events[0];
+    hipEvent_t *ev_sampled = &c->split_events[1], *ev_windowed = &c->split_events[1 + MAXG];
+
+    amvs::StepArgs all = base_args(c, p->patch_size, n_ref, TH);
+    all.fast = 1;
+    all.depth_min = p->depth_min; all.depth_max = p->depth_max;
+    all.seed = seed;
+    all.samples = c->d_samples;
+    all.half = p->patch_size / 2;
+    all.s_TH = s_TH;
+    all.s_lds = c->split_sample_lds;
+    all.s_tiles_x = (c->W + 63) / 64;
+    all.s_tiles_y = (c->H + s_TH - 1) / s_TH;
+    int cur = 0, cur_n = 0;
+    HIPCHK(c, amvs::launch_init(all.jobs, n_ref, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
+                                c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_groups[0], c->stream));
+    HIPCHK(c, hipEventRecord(ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(s_smp, ev_fork, 0));
+    HIPCHK(c, hipStreamWaitEvent(s_win, ev_fork, 0));
+    bool first = true;
+    for (const SchedStep &st : sched) {
+        for (int g = 0; g < G; ++g) {
+            const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
+            amvs::StepArgs a = all;
+            a.n_jobs = nj;
+            a.jobs = c->d_jobs + j0;
+            apply_step(a, st);
+            set_io(a, c, cur, cur_n);
+            if (!first) HIPCHK(c, hipStreamWaitEvent(s_smp, ev_windowed[g], 0));
+            HIPCHK(c, amvs::launch_sample_fast(n_src, a, s_smp));
+            HIPCHK(c, hipEventRecord(ev_sampled[g], s_smp));
+            HIPCHK(c, hipStreamWaitEvent(s_win, ev_sampled[g], 0));
+            a.presampled = 1;
+            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, s_win));
+            HIPCHK(c, hipEventRecord(ev_windowed[g], s_win));
+        }
+        first = false;
+        cur ^= st.flip_d; cur_n ^= st.flip_n;
+    }
+    // the window stream is in order, so its last event covers every group
+    if (!sched.empty()) HIPCHK(c, hipStreamWaitEvent(c->stream, ev_windowed[G - 1], 0));
+    HIPCHK(c, hipEventRecord(c->ev_groups[1], c->stream));
+    // _compute_confidence (mvs_patchmatch.py:493-534): one fused launch over the whole batch
+    all.mode = amvs::MODE_CONF;
+    set_io(all, c, cur, cur_n);
+    all.aux = (float *)conf_dev;
+    HIPCHK(c, amvs::launch_step(p->patch_size, n_src, all, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_groups[2], c->stream));
+    c->timing.sweep_launches = (int64_t)sched.size();     // one hypothesis of the whole batch each
+    c->last_views_per_launch = n_ref;
+    return AMVS_OK;
+}
+
 // single-view, single-step helper for the test entry points
 struct OneStep {
     amvs_ctx *c;
@@ -489,6 +695,9 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_xcand_d) (void)hipFree(c->d_xcand_d);
     if (c->d_xcand_n) (void)hipFree(c->d_xcand_n);
     if (c->d_xsrc) (void)hipFree(c->d_xsrc);
+    if (c->d_samples) (void)hipFree(c->d_samples);
+    for (auto &st : c->split_streams) (void)hipStreamDestroy(st);
+    for (auto &ev : c->split_events) (void)hipEventDestroy(ev);
     if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
     if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
     if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
@@ -652,82 +861,26 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src, fast ? p->patch_size : 0))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
-    // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
-    // `vpl` views, each group through the whole schedule (see default_views_per_launch).
-    int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
-    if (vpl > n_ref) vpl = n_ref;
-    if (p->schedule < 0 || p->schedule > 2) return fail(c, AMVS_EINVAL, "unknown schedule");
-    const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
-    const int TH = p->tile_rows > 0 || !band_major
-                       ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0)
-                       : pick_band_rows(c, p->patch_size, n_src, vpl, fast != 0);
-    c->last_tile_rows = TH;
+    if (p->schedule < 0 || p->schedule > AMVS_SCHEDULE_SPLIT) return fail(c, AMVS_EINVAL, "unknown schedule");
+    if (p->schedule == AMVS_SCHEDULE_SPLIT && !fast)
+        return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists in fast mode only");
     resolve_timing(c);
     c->timing = amvs_timing{};
-    const int n_groups = (n_ref + vpl - 1) / vpl;
-    // events: [0] start, then per group: after init, after steps, after confidence
-    while ((int)c->ev_groups.size() < 3 * n_groups) {
-        hipEvent_t ev;
-        HIPCHK(c, hipEventCreate(&ev));
-        c->ev_groups.push_back(ev);
-    }
-    c->timing_groups = n_groups;
-
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    const std::vector<SchedStep> sched = build_schedule(p);
     int cur = 0, cur_n = 0;
-    int64_t launches = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        const int j0 = g * vpl, nj = (n_ref - j0) < vpl ? (n_ref - j0) : vpl;
-        amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
-        a.fast = fast;
-        a.band_major = band_major;
-        a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
-        a.depth_min = p->depth_min; a.depth_max = p->depth_max;
-        a.seed = seed;
-        cur = 0; cur_n = 0;
-        // initialisation (mvs_patchmatch.py:268-284)
-        HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
-                                    c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
-        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g], c->stream));
-        for (int it = 0; it < p->num_iterations; ++it) {
-            // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
-            // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
-            const int sgn = (it % 2 == 0) ? 1 : -1;
-            for (int k = 0; k < 2; ++k) {
-                a.mode = amvs::MODE_PROP;
-                a.oy = k == 0 ? sgn : 0;
-                a.ox = k == 0 ? 0 : sgn;
-                set_io(a, c, cur, cur_n);
-                HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-                cur ^= 1; cur_n ^= 1; ++launches;
-            }
-            // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
-            a.mode = amvs::MODE_REFINE;
-            a.depth_range = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
-            a.normal_range = (float)(0.5 * std::pow(0.5, it));
-            for (int s = 0; s < p->num_samples; ++s) {
-                a.draw = (unsigned)(1 + it * p->num_samples + s);
-                set_io(a, c, cur, cur_n);
-                HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-                cur ^= 1; ++launches;
-            }
-        }
-        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 1], c->stream));
-        // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
-        a.mode = amvs::MODE_CONF;
-        set_io(a, c, cur, cur_n);
-        a.aux = (float *)conf_dev;
-        HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
+    for (const SchedStep &st : sched) { cur ^= st.flip_d; cur_n ^= st.flip_n; }   // final buffers
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (p->schedule == AMVS_SCHEDULE_SPLIT) {
+        if ((rc = run_split_schedule(c, n_ref, n_src, p, seed, sched, conf_dev))) return rc;
+    } else {
+        if ((rc = run_fused_schedule(c, n_ref, n_src, p, seed, fast, sched, conf_dev))) return rc;
     }
     // every group ran the same schedule, so the final buffers (cur, cur_n) are the same for all
     HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    c->timing.sweep_launches = launches;
     c->timing.pixel_hypotheses =
         (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
-    c->last_views_per_launch = vpl;
     c->timing_pending = true;
     return AMVS_OK;
 }
@@ -797,6 +950,15 @@ int amvs_set_sweep_tuning(amvs_ctx *c, int tile_rows, int chunk)
     if (tile_rows < 0 || tile_rows > AMVS_SWEEP_MAX_TH || chunk < 0)
         return fail(c, AMVS_EINVAL, "plane-sweep tuning out of range");
     c->sweep_tile_rows = tile_rows; c->sweep_chunk = chunk;
+    return AMVS_OK;
+}
+
+int amvs_set_split_tuning(amvs_ctx *c, int groups, int sample_rows, int sample_lds_bytes)
+{
+    if (!c) return AMVS_EINVAL;
+    if (groups < 0 || groups > 8 || sample_rows < 0 || sample_lds_bytes < 0 || sample_lds_bytes > 64 * 1024)
+        return fail(c, AMVS_EINVAL, "split tuning out of range");
+    c->split_groups = groups; c->split_sample_rows = sample_rows; c->split_sample_lds = sample_lds_bytes;
     return AMVS_OK;
 }
 
@@ -907,10 +1069,7 @@ int amvs_plane_sweep_batch(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
     if (n_ref > c->cap_sweep) {
-        if (c->d_xcand_d) (void)hipFree(c->d_xcand_d);
-    if (c->d_xcand_n) (void)hipFree(c->d_xcand_n);
-    if (c->d_xsrc) (void)hipFree(c->d_xsrc);
-    if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
+        if (c->d_sweep_depth) (void)hipFree(c->d_sweep_depth);
         if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
         c->d_sweep_depth = c->d_sweep_conf = nullptr; c->cap_sweep = 0;
         HIPCHK(c, hipMalloc(&c->d_sweep_depth, 4 * hw * n_ref));

@@ -76,6 +76,13 @@ struct StepArgs : StepArgsBase {
     float depth_min, depth_max, depth_range, normal_range;
     unsigned long long seed;
     unsigned draw;
+    // Split schedule (fast mode): sample maps [slot][n_src][H*W] written by launch_sample_fast and
+    // read by launch_step when `presampled`; the sampling kernel's own strips (64 columns, no halo).
+    float *samples;
+    int presampled;
+    int half;                                // patch_size / 2
+    int s_TH, s_tiles_x, s_tiles_y;
+    int s_lds;                               // unused dynamic LDS per sampling workgroup (occupancy cap); 0 = default
 };
 
 struct SweepArgs : StepArgsBase {
@@ -99,6 +106,7 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
 // amvs_kernels_fast.hip: the same steps in the fast arithmetic (a.fast != 0; launch_step /
 // launch_sweep forward to these)
 hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st);
+hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st);      // split schedule, first half
 hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st);
 int step_fast_waves_per_cu(int K, int S);
 // test hook: per-source samples [S][H*W] and validity bits [H*W] of job 0 at the depth map a.d_in;

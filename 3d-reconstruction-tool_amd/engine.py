@@ -78,6 +78,11 @@ class Engine:
     def set_sweep_tuning(self, tile_rows=0, planes_per_wave=0):
         self._chk(self._lib.amvs_set_sweep_tuning(self._h, int(tile_rows), int(planes_per_wave)))
 
+    def set_split_tuning(self, groups=0, sample_rows=0, sample_lds_bytes=0):
+        """Split schedule (schedule="split"): view groups pipelined against each other, rows per strip
+        of the sampling kernel, unused LDS bytes per sampling workgroup; 0 = automatic."""
+        self._chk(self._lib.amvs_set_split_tuning(self._h, int(groups), int(sample_rows), int(sample_lds_bytes)))
+
     # -- lifecycle ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):

@@ -125,7 +125,10 @@ def main():
     ap.add_argument("--planes", type=int, default=64)
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
                     help="arithmetic of the sweep kernels (include/amvs.h AMVS_MODE_*)")
-    ap.add_argument("--schedule", choices=["auto", "view-major", "band-major"], default="auto",
+    ap.add_argument("--split-groups", type=int, default=0, help="split schedule: view groups (0 = automatic)")
+    ap.add_argument("--split-lds", type=int, default=0, help="split schedule: unused LDS bytes per sampling workgroup (0 = automatic)")
+    ap.add_argument("--split-rows", type=int, default=0, help="split schedule: rows per sampling strip (0 = automatic)")
+    ap.add_argument("--schedule", choices=["auto", "view-major", "band-major", "split"], default="auto",
                     help="strip order of the sweep launches (amvs_pm_params.schedule)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")
@@ -196,6 +199,7 @@ def main():
         torch.cuda.synchronize()
     params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
                             args.views_per_launch, schedule=args.schedule)
+    eng.set_split_tuning(args.split_groups, args.split_rows, args.split_lds)
     n_loc = len(mine)
     if world > 1:
         assert n_views % world == 0, "the bench shards equal blocks: --scene-views must be a multiple of --gpus"

@@ -65,9 +65,16 @@ typedef struct {
     float   depth_min, depth_max;
     float   log_depth_scale, log_depth_min;
     int32_t mode;             /* AMVS_MODE_DEFAULT / _EXACT / _FAST                    */
-    int32_t schedule;         /* strip order: 0 = automatic, 1 = view-major, 2 = band-major
-                                 (performance only; results do not depend on it)       */
+    int32_t schedule;         /* AMVS_SCHEDULE_*: 0 = automatic, 1 = view-major strips, 2 = band-major
+                                 strips, 3 = split (fast mode only: sampling kernel + window kernel,
+                                 pipelined over view groups).  Performance only; results do not
+                                 depend on it.                                          */
 } amvs_pm_params;
+
+#define AMVS_SCHEDULE_AUTO        0
+#define AMVS_SCHEDULE_VIEW_MAJOR  1
+#define AMVS_SCHEDULE_BAND_MAJOR  2
+#define AMVS_SCHEDULE_SPLIT       3
 
 /* Per-call device timing of the sweep kernels (HIP events on the context
  * stream; used by bench.py for the roofline figure).                            */
@@ -133,6 +140,10 @@ int amvs_set_mode(amvs_ctx *ctx, int mode);
 int amvs_get_mode(const amvs_ctx *ctx);
 /* Plane-sweep launch shape: rows per wave strip (1..32) and planes per wave; 0 = automatic.   */
 int amvs_set_sweep_tuning(amvs_ctx *ctx, int tile_rows, int planes_per_wave);
+/* Split schedule (AMVS_SCHEDULE_SPLIT): number of view groups pipelined against each other (1..8),
+ * rows per strip of the sampling kernel, and bytes of unused LDS per sampling workgroup (caps how
+ * many of them a CU holds, which leaves room for the window kernel); 0 = automatic.              */
+int amvs_set_split_tuning(amvs_ctx *ctx, int groups, int sample_rows, int sample_lds_bytes);
 /* Rows per wave strip the last sweep used (amvs_pm_params.tile_rows, or the automatic choice). */
 int amvs_last_tile_rows(const amvs_ctx *ctx);
 /* Views per launch group the last PatchMatch call used (amvs_pm_params.views_per_launch or auto). */

@@ -1,3 +1,8 @@
+// NOT BUILT -- kept as evidence for DESIGN.md section 5: the software-pipelined row loop of the fast sweep
+// step (stage A of row r+1 and the state loads of row r+2 ahead of stage B of row r, two register sets
+// alternated at compile time, explicit s_waitcnt vmcnt(N)).  Measured 0.867 ms per launch against 0.814
+// for the unpipelined kernel (16 views 1080p, k=7, S=4), so it was not adopted.  Written against the
+// headers of commit ac2fc2e; swap it for csrc/amvs_kernels_fast.hip there to rebuild it.
 // amvs_kernels_fast.hip -- the sweep kernels in the FAST (tolerance) arithmetic, AMVS_MODE_FAST.
 //
 // Same algorithm, same execution shape and same RNG / candidate / select logic as
@@ -33,24 +38,27 @@ namespace amvs {
 #ifndef AMVS_FAST_MIN_WAVES_BIAS
 #define AMVS_FAST_MIN_WAVES_BIAS 0
 #endif
-// Resident workgroups per CU of the sweep step, enforced through unused dynamic LDS (160 KiB /
-// (static + extra)).  Fewer resident waves touch fewer source rows at once: measured on MI355X
-// (16 views 1080p, k=7, S=4, ms per launch) 6 workgroups = 24 waves per CU 0.897, 5: 0.822, 4: 0.814,
-// 3: 0.856 -- the launch is bound by the CU's L1 line rate for scattered gathers (2 cycles per distinct
-// 128-byte line, tools/gather_rate.hip), not by latency, so the extra waves only add L2 misses.
-#ifndef AMVS_FAST_MAX_WGS_PER_CU
-#define AMVS_FAST_MAX_WGS_PER_CU 4
+// extra dynamic LDS per workgroup of the sweep step: caps the resident workgroups per CU
+// (160 KiB / (static + extra)); fewer resident waves touch fewer source rows at once
+#ifndef AMVS_FAST_STEP_EXTRA_LDS
+#define AMVS_FAST_STEP_EXTRA_LDS 0
 #endif
+
+// reload() of amvs_kernel_common.h with the pointer first forced into SGPRs: inside the unrolled,
+// software-pipelined loop hipcc no longer proves the job pointer uniform at every use and rejects
+// the plain "+s" constraint ("illegal VGPR to SGPR copy"); v_readfirstlane is free when it is.
+AMVS_DEV JobCP reload_u(JobCP p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (JobCP)(((unsigned long long)hi << 32) | lo);
+}
 
 template <int S> struct FRing {
     static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
     static constexpr int NR = S - NL > 0 ? S - NL : 1;
-};
-
-template <int K, int S> struct StepLds {
-    static constexpr unsigned STATIC = AMVS_WG_WAVES * ((FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u);
-    static constexpr unsigned SHARE = 160u * 1024u / AMVS_FAST_MAX_WGS_PER_CU;
-    static constexpr unsigned EXTRA = STATIC < SHARE ? SHARE - STATIC : 0u;
 };
 
 // the last K reference codes of a lane's column as packed bytes: the window occupies the TOP K
@@ -195,6 +203,56 @@ AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, float fx,
     return okbits;
 }
 
+// The same in two halves for the software-pipelined sweep step: geometry + gather ISSUE of a row now,
+// decode + interpolation one loop iteration later (the gathers' latency then overlaps the previous
+// row's window / NCC / select work of the same wave).  A row in flight = 2 weights + 1 raw dword per
+// source.
+struct FastTap2 { float wx, wy; };
+
+template <int S, bool LEAN, bool BOUNDED>
+AMVS_DEV unsigned fast_issue_sources(JobCP job, const FastConsts &fc, float fx, float fy, float d,
+                                     FastTap2 (&tw)[S], uint32_t (&raw)[S], bool &ok)
+{
+    unsigned okbits = 0u;
+    float zlo = 1.0f, zhi = 1.0f;
+    JobCP jr = job;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s % AMVS_FAST_RELOAD_STRIDE == 0) jr = reload_u(jr);
+        float M[9], b[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = jr->fsrc[s].M[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = jr->fsrc[s].b[i];
+        const unsigned long long img = jr->fsrc[s].pairs;
+        bool valid;
+        const FastTap t = fast_geom<LEAN, BOUNDED>(M, b, fc, fx, fy, d, valid, zlo, zhi);
+        okbits |= valid ? (1u << s) : 0u;
+        tw[s].wx = t.wx; tw[s].wy = t.wy;
+        raw[s] = fast_load(img, t.off);
+    }
+    if constexpr (LEAN) ok = (zlo >= 0x1p-95f) & (zhi < 0x1p96f);
+    return okbits;
+}
+
+template <int S, bool BOUNDED>
+AMVS_DEV unsigned fast_issue_sources_checked(JobCP job, const FastConsts &fc, float fx, float fy, float d,
+                                             FastTap2 (&tw)[S], uint32_t (&raw)[S])
+{
+    bool ok = true;
+    unsigned okbits = fast_issue_sources<S, true, BOUNDED>(job, fc, fx, fy, d, tw, raw, ok);
+    if (__builtin_expect(!__all(ok), 0))
+        okbits = fast_issue_sources<S, false, BOUNDED>(reload_u(job), fc, fx, fy, d, tw, raw, ok);
+    return okbits;
+}
+
+AMVS_DEV float fast_finish2(uint32_t w, const FastTap2 &t, bool live)
+{
+    FastTap f;
+    f.wx = t.wx; f.wy = t.wy; f.off = 0;
+    return fast_finish(w, f, live);
+}
+
 // optimistic lean reciprocals first, IEEE repeat if some lane's z left the verified range
 template <int S, bool BOUNDED>
 AMVS_DEV unsigned fast_sample_sources_checked(JobCP job, const FastConsts &fc, float fx, float fy, float d,
@@ -264,87 +322,13 @@ AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr)
 
 constexpr int fast_min_waves(int K, int S)
 {
+    // (four waves per SIMD: the pipelined loop holds two rows in flight -- ~100-125 VGPRs -- and more
+    // resident waves only widen the band of source rows an XCD touches at once)
     return ((S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_FAST_MIN_WAVES_BIAS;
 }
 
-// Depth hypothesis a pixel is sampled at in this step: the (offset) pixel's current depth for
-// propagation / evaluation / confidence, a clamped random perturbation of it for refinement
-// (mvs_patchmatch.py:430-436, :468-473).  `d_raw` is d_in at the pixel (+ offset) when `inb`.
-AMVS_DEV float candidate_depth(const StepArgs &a, int mode, bool inb, float d_raw, uint32_t h0)
-{
-    const float dc = inb ? d_raw : a.depth_min;
-    const float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
-    float d = dc + delta;
-    d = d < a.depth_min ? a.depth_min : d;
-    d = d > a.depth_max ? a.depth_max : d;
-    return mode == MODE_REFINE ? d : dc;
-}
-
-// Sample maps of the split schedule (StepArgs::samples): [slot][source][H*W] floats, the sampled
-// value in code units (>= 0 or NaN) with the validity of the projection in the sign bit (set = invalid).
-AMVS_DEV uint32_t sample_encode(float v, bool ok)
-{
-    return (__float_as_uint(v) & 0x7FFFFFFFu) | (ok ? 0u : 0x80000000u);
-}
-
-// ------------------------------------------------------------------ sampling step ---
-// First half of a split sweep step: every pixel of the launch's views once, NO strip halo --
-// hypothesis, projection into the S sources, bilinear sample -> the sample maps.  The launch is
-// bound by the CU's L1 line rate (2 cycles per gathered 128-byte line); the window / NCC / select
-// half (pm_step_fast_kernel<..., PRE = true>) streams the sample maps and runs concurrently with
-// the sampling half of another view group (amvs_capi.hip, run_split_schedule).
-template <int S, int MODE_T>
-__global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kernel(const StepArgs a)
-{
-    const int lane = threadIdx.x & (AMVS_WAVE - 1);
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
-    const int per_job = a.s_tiles_x * a.s_tiles_y;
-    const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
-    if (t >= a.n_jobs * per_job) return;                       // last workgroup only
-    const int job_id = t / per_job;
-    const int rem = t - job_id * per_job;
-    const int ty = rem / a.s_tiles_x, tx = rem - ty * a.s_tiles_x;
-
-    const JobCP job = (JobCP)(a.jobs + job_id);
-    const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
-    const long long HW = (long long)H * W;
-    const float *__restrict__ d_in = a.d_in + job->slot * HW;
-    uint32_t *__restrict__ out = (uint32_t *)a.samples + job->slot * HW * S;
-    const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
-    const FastConsts fc = make_fast_consts(H, W, mode == MODE_CONF ? 0 : a.half);
-
-    const int xr = tx * AMVS_WAVE + lane;
-    const int y0 = ty * a.s_TH;
-    const float fx = (float)xr;
-    const bool col_in = xr < W;
-    const int rows = min(a.s_TH, H - y0);
-    const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
-    const int noff = oy * W + ox;
-
-    for (int r = 0; r < rows; ++r) {
-#if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
-        if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
-#endif
-        const int yr = y0 + r;
-        const bool live = col_in;
-        const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
-        const int pix = yr * W + xr;
-        const float d_raw = d_in[inb ? pix + noff : 0];
-        const uint32_t h0 = pixel_hash((uint32_t)pix, key);
-        const float dc = candidate_depth(a, mode, inb, d_raw, h0);
-        float v[S];
-        const unsigned okbits = fast_sample_sources_checked<S, true>(job, fc, fx, (float)yr, dc, live, v);
-        if (live) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) out[s * HW + pix] = sample_encode(v[s], (okbits >> s) & 1u);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ sweep step ---
-// PRE: the samples come from the sample maps written by pm_sample_fast_kernel (split schedule)
-// instead of being gathered here; everything after the sampling stage is the same code.
-template <int K, int S, int MODE_T, bool PRE = false>
+template <int K, int S, int MODE_T>
 __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) void pm_step_fast_kernel(const StepArgs a)
 {
     constexpr int HALF = K / 2;
@@ -372,7 +356,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const long long HW = (long long)H * W;
     constexpr int PADW = 2 * AMVS_PAIR_BORDER;
     // (global address space: a generic pointer would make these FLAT loads, which force vmcnt(0) and
-    // lgkmcnt(0) waits)
+    // lgkmcnt(0) waits and would serialise the pipelined loop)
     const GlobalU16 ref_pairs = (GlobalU16)job->ref_pairs;
     const GlobalFloat2s ref_stats = (GlobalFloat2s)job->ref_stats;
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
@@ -381,7 +365,6 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     float *cost_io = a.cost + job->slot * HW;
     float *n_out = a.n_out + job->slot * HW * 3;
     float *__restrict__ aux = a.aux + job->slot * HW;
-    const uint32_t *__restrict__ smp = PRE ? (const uint32_t *)a.samples + job->slot * HW * S : nullptr;
 
     const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
     // validity window of the projection: patch bounds (mvs_patchmatch.py:362-363) or image bounds
@@ -412,131 +395,195 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
     const int noff = oy * W + ox;
 
-    for (int r = 0; r < rows; ++r) {
-#if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
-        if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
-#endif
+    // ------------------------------------------------------------------------------------------
+    // Software-pipelined row loop.  A wave's row used to be a serial chain load -> geometry ->
+    // gather -> window -> select with two or three exposed memory latencies (~1 us each under load):
+    // measured, a wave spent 53 % of its lifetime in s_waitcnt and the launch time did not react to
+    // removing a third of its VALU work.  More resident waves do not help either -- they widen the
+    // band of source rows the XCD touches at once and the L2 hit rate falls.
+    // So every memory access is issued at least one loop iteration before its use:
+    //     iteration r:  1. request the state of row r+2 (candidate depth, ref code) and the output
+    //                      pixel's state of row r+1 (old depth / cost, ref statistics, normals)
+    //                   2. stage A of row r+1: candidate, hash, geometry, ISSUE the S gathers
+    //                   3. stage B of row r:   decode, rings, window sums, NCC, select, stores
+    // ------------------------------------------------------------------------------------------
+    struct RowState { float d_raw; uint32_t rc_raw; };
+    struct RowSamples { FastTap2 tw[S]; uint32_t raw[S]; unsigned okbits; uint32_t h0, rcode; };   // rcode bit 8: pixel inside the image
+    struct OutState { float oldd, oldc; f32x2_t mv1; float nb_d, nc0, nc1, nc2, nn0, nn1, nn2; };
+
+    auto request_row = [&](int r, RowState &o) {
         const int yr = y0 - HALF + r;
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
-        const uint32_t h0 = pixel_hash((uint32_t)pix, key);
-        float v[S];
-        unsigned okbits = 0u;
-        if constexpr (PRE) {
-            const uint32_t *__restrict__ sp = smp + (live ? pix : 0);
-            uint32_t w[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) w[s] = sp[s * HW];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                v[s] = live ? __uint_as_float(w[s] & 0x7FFFFFFFu) : 0.0f;
-                okbits |= (w[s] >> 31) ? 0u : (1u << s);
-            }
-        } else {
-            // ---- candidate depth of this (possibly halo) pixel: as in the exact kernel ----
-            const float d_raw = d_in[inb ? pix + noff : 0];
-            const float dc = candidate_depth(a, mode, inb, d_raw, h0);
-            okbits = fast_sample_sources_checked<S, true>(job, fc, fx, (float)yr, dc, live, v);
-        }
-        const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
-
-        // ---- push into the vertical rings ----
-        ref_bytes_push<K>(rb, rcode);
-        fring_push<K, S>(lring, lane, wslot, ring_v, v);
-        wslot = wslot + 1 == K ? 0 : wslot + 1;
-        hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
-#pragma unroll
-        for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
-        hist_h0[HALF] = h0;
-
-        if (r < 2 * HALF) continue;
-
-        // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
-        const int yc = yr - HALF;
-        const int xc = xr + HALF;
-        const bool outl = (lane < OUTW) & (xc < W);
+        o.d_raw = d_in[inb ? pix + noff : 0];
+        o.rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
+    };
+    auto request_out = [&](int r, OutState &o) {               // output pixel of stage B of row r
+        const int yc = y0 - HALF + r - HALF, xc = xr + HALF;
+        const bool outl = (lane < OUTW) & (xc < W) & (r >= 2 * HALF);
         const int pc = outl ? yc * W + xc : 0;
-        const float oldd = d_in[pc], oldc = cost_io[pc];
-        const f32x2_t mv1 = ref_stats[pc];
-        const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
-        const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
-
-        float rr[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) rr[i] = ref_bytes_get<K>(rb, i);
-        float bvs[S], bvvs[S], brvs[S];
-        window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
-        const float m1 = mv1.x, v1 = mv1.y;
-
-        float total = 0.0f, cnt = 0.0f;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            // _ncc_cost (mvs_patchmatch.py:403-411), sums in code units
-            const float mean2 = bvs[s] * C1;
-            const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
-            const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
-            float den, rden;
-            ncc_denominator(v1 * var2, den, rden);
-            const float cost = 1.0f - cov * rden;
-            const bool oks = (okc >> s) & 1u;
-            const float ncc2 = 1.0f - cost;                         // :530
-            const bool hit = mode == MODE_CONF ? (oks & (ncc2 > 0.6f)) : oks;
-            total = (hit & (mode != MODE_CONF)) ? total + cost : total;
-            cnt = hit ? cnt + 1.0f : cnt;
-        }
-        const bool act = outl;
-
-        if (mode == MODE_CONF) {
-            if (act) aux[pc] = cnt;
-            continue;
-        }
-
-        // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
-        const float cden = cnt + 1e-8f;
-        bool cden_ok = true;
-        const float avg = total * rcp_t<true>(cden, cden_ok);
-        const float newc = cnt >= 2.0f ? avg : __builtin_inff();
-        if (mode == MODE_EVAL) {
-            if (act) aux[pc] = newc;
-            continue;
-        }
-
-        // ---- select (mvs_patchmatch.py:452-455 / :486-489): as in the exact kernel ----
-        const bool better = act & (newc < oldc);
-        if (better) cost_io[pc] = newc;
+        o.oldd = d_in[pc];
+        o.oldc = cost_io[pc];
+        o.mv1 = ref_stats[pc];
         if (mode == MODE_PROP) {
+            // both normals the select may take (its own, the neighbour's) and the neighbour's depth
             const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-            const int pn = inb_c ? pc + noff : 0;
-            const int ps = better ? pn : pc;
-            const float nb_d = d_in[pn];
-            float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
-            const bool zero = better & !inb_c;
-            if (act) {
-                d_out[pc] = better ? (inb_c ? nb_d : a.depth_min) : oldd;
-                n_out[3 * pc] = zero ? 0.0f : t0;
-                n_out[3 * pc + 1] = zero ? 0.0f : t1;
-                n_out[3 * pc + 2] = zero ? 0.0f : t2;
-            }
-        } else {
-            float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
-            float d = oldd + delta;
+            const int pn = (outl & inb_c) ? pc + noff : 0;
+            o.nb_d = d_in[pn];
+            o.nc0 = n_in[3 * pc]; o.nc1 = n_in[3 * pc + 1]; o.nc2 = n_in[3 * pc + 2];
+            o.nn0 = n_in[3 * pn]; o.nn1 = n_in[3 * pn + 1]; o.nn2 = n_in[3 * pn + 2];
+        }
+    };
+    auto stage_a = [&](int r, const RowState &st, RowSamples &o) {
+        const int yr = y0 - HALF + r;
+        const bool live = col_in & ((unsigned)yr < (unsigned)H);
+        const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
+        const int pix = yr * W + xr;
+        // candidate depth of this (possibly halo) pixel: as in the exact kernel
+        float dc = inb ? st.d_raw : a.depth_min;
+        const uint32_t h0 = pixel_hash((uint32_t)pix, key);
+        {
+            float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
+            float d = dc + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            if (act) d_out[pc] = better ? d : oldd;
-            const unsigned long long won = __ballot(better);
-            if (won != 0ull) {
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
-                q_tail += __popcll(won);
-                if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
-                    q_head += AMVS_WAVE;
+            dc = mode == MODE_REFINE ? d : dc;
+        }
+        o.h0 = h0;
+        o.rcode = live ? ((st.rc_raw & 0xFFu) | 0x100u) : 0u;
+        o.okbits = fast_issue_sources_checked<S, true>(job, fc, fx, (float)yr, dc, o.tw, o.raw);
+    };
+
+    // Two register sets used alternately (compile-time parity, loop unrolled by two): copying a set
+    // would read the destination registers of loads still in flight and force the wait the pipeline
+    // is there to avoid.  Invariant at the start of iteration r (p = r & 1): smp[p] / os[p] belong to
+    // row r (gathers in flight), st[1-p] holds the requested state of row r+1.
+    RowState st[2];
+    RowSamples smp[2];
+    OutState os[2];
+    request_row(0, st[0]);
+    request_row(1 < rows ? 1 : 0, st[1]);
+    stage_a(0, st[0], smp[0]);
+    request_out(0, os[0]);
+
+    auto iteration = [&](const int r, auto parity) {
+        constexpr int p = decltype(parity)::value;
+        RowSamples &smp_c = smp[p];
+        OutState &os_c = os[p];
+#if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
+        if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
+#endif
+        // ---- 1 + 2: requests for the next rows, stage A of row r+1 ----
+        // Unconditional, with clamped row indices (the last iteration repeats the last row's stage A
+        // and discards it): a path through the loop body that issues no loads would make hipcc's
+        // s_waitcnt insertion assume the worst case -- the gathers of row r being the youngest
+        // outstanding loads -- and drain the whole queue, row r+1's gathers included, before stage B.
+        {
+            const int rn = r + 1 < rows ? r + 1 : rows - 1, rnn = r + 2 < rows ? r + 2 : rows - 1;
+            request_row(rnn, st[p]);
+            request_out(rn, os[1 - p]);
+            stage_a(rn, st[1 - p], smp[1 - p]);
+        }
+
+        // ---- 3: stage B of row r ----
+        const int yr = y0 - HALF + r;
+        float v[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) v[s] = fast_finish2(smp_c.raw[s], smp_c.tw[s], (smp_c.rcode & 0x100u) != 0u);
+        ref_bytes_push<K>(rb, smp_c.rcode & 0xFFu);
+        fring_push<K, S>(lring, lane, wslot, ring_v, v);
+        wslot = wslot + 1 == K ? 0 : wslot + 1;
+        hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)smp_c.okbits << (S * HALF));
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
+        hist_h0[HALF] = smp_c.h0;
+
+        if (r >= 2 * HALF) {
+            // window sums, NCC, aggregate for centre row yc and centre column xc
+            const int yc = yr - HALF;
+            const int xc = xr + HALF;
+            const bool outl = (lane < OUTW) & (xc < W);
+            const int pc = outl ? yc * W + xc : 0;
+            const float oldd = os_c.oldd, oldc = os_c.oldc;
+            const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
+            const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
+
+            float rr[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) rr[i] = ref_bytes_get<K>(rb, i);
+            float bvs[S], bvvs[S], brvs[S];
+            window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
+            const float m1 = os_c.mv1.x, v1 = os_c.mv1.y;
+
+            float total = 0.0f, cnt = 0.0f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                // _ncc_cost (mvs_patchmatch.py:403-411), sums in code units
+                const float mean2 = bvs[s] * C1;
+                const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
+                const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
+                float den, rden;
+                ncc_denominator(v1 * var2, den, rden);
+                const float cost = 1.0f - cov * rden;
+                const bool oks = (okc >> s) & 1u;
+                const float ncc2 = 1.0f - cost;                         // :530
+                const bool hit = mode == MODE_CONF ? (oks & (ncc2 > 0.6f)) : oks;
+                total = (hit & (mode != MODE_CONF)) ? total + cost : total;
+                cnt = hit ? cnt + 1.0f : cnt;
+            }
+            const bool act = outl;
+
+            if (mode == MODE_CONF) {
+                if (act) aux[pc] = cnt;
+            } else {
+                // average over valid sources, +inf when fewer than two (mvs_patchmatch.py:387-388)
+                const float cden = cnt + 1e-8f;
+                bool cden_ok = true;
+                const float avg = total * rcp_t<true>(cden, cden_ok);
+                const float newc = cnt >= 2.0f ? avg : __builtin_inff();
+                if (mode == MODE_EVAL) {
+                    if (act) aux[pc] = newc;
+                } else {
+                    // ---- select (mvs_patchmatch.py:452-455 / :486-489): as in the exact kernel ----
+                    const bool better = act & (newc < oldc);
+                    if (better) cost_io[pc] = newc;
+                    if (mode == MODE_PROP) {
+                        const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
+                        const bool zero = better & !inb_c;
+                        const float t0 = better ? os_c.nn0 : os_c.nc0, t1 = better ? os_c.nn1 : os_c.nc1,
+                                    t2 = better ? os_c.nn2 : os_c.nc2;
+                        if (act) {
+                            d_out[pc] = better ? (inb_c ? os_c.nb_d : a.depth_min) : oldd;
+                            n_out[3 * pc] = zero ? 0.0f : t0;
+                            n_out[3 * pc + 1] = zero ? 0.0f : t1;
+                            n_out[3 * pc + 2] = zero ? 0.0f : t2;
+                        }
+                    } else {
+                        float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
+                        float d = oldd + delta;
+                        d = d < a.depth_min ? a.depth_min : d;
+                        d = d > a.depth_max ? a.depth_max : d;
+                        if (act) d_out[pc] = better ? d : oldd;
+                        const unsigned long long won = __ballot(better);
+                        if (won != 0ull) {
+                            const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
+                            if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
+                            q_tail += __popcll(won);
+                            if (q_tail - q_head >= AMVS_WAVE) {
+                                refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
+                                q_head += AMVS_WAVE;
+                            }
+                        }
+                    }
                 }
             }
         }
+    };
+    for (int r = 0; r < rows; r += 2) {
+        iteration(r, std::integral_constant<int, 0>{});
+        if (r + 1 < rows) iteration(r + 1, std::integral_constant<int, 1>{});
     }
     if (mode == MODE_REFINE) {
         while (q_tail - q_head > 0) {
@@ -577,7 +624,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const long long HW = (long long)H * W;
     constexpr int PADW = 2 * AMVS_PAIR_BORDER;
     // (global address space: a generic pointer would make these FLAT loads, which force vmcnt(0) and
-    // lgkmcnt(0) waits)
+    // lgkmcnt(0) waits and would serialise the pipelined loop)
     const GlobalU16 ref_pairs = (GlobalU16)job->ref_pairs;
     const GlobalFloat2s ref_stats = (GlobalFloat2s)job->ref_stats;
     const FastConsts fc = make_fast_consts(H, W, 0);
@@ -631,34 +678,21 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
             const float m1 = mv1.x, v1 = mv1.y;
             uint32_t votes = 0u;
-            if (a.thresh > 0.0f) {
-                // ncc > thresh (dense_stereo.py:303) without square root and division:
-                // cov / sqrt(x) > t  <=>  cov > 0, x >= 0 (a negative x is the reference's NaN) and cov^2 > t^2 x
-                const float t2 = a.thresh * a.thresh;
+            auto vote_stage = [&](auto lean, bool &ok) {
+                constexpr bool LEAN = decltype(lean)::value;
+                votes = 0u;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
+                    // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
                     const float mean2 = bvs[s] * C1;
                     const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
                     const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
-                    const float x = v1 * var2 + 1e-8f;
-                    const bool vote = (cov > 0.0f) & (x >= 0.0f) & (cov * cov > t2 * x) & (((okc >> s) & 1u) != 0u);
-                    votes += vote ? 1u : 0u;
+                    const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
+                    const float ncc = cov * rcp_t<LEAN>(den, ok);
+                    if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
                 }
-            } else {
-                auto vote_stage = [&](auto lean, bool &ok) {
-                    constexpr bool LEAN = decltype(lean)::value;
-                    votes = 0u;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
-                        const float mean2 = bvs[s] * C1;
-                        const float var2 = __builtin_fmaf(-mean2, mean2, bvvs[s] * C2);
-                        const float cov = __builtin_fmaf(-m1, mean2, brvs[s] * C2);
-                        const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
-                        const float ncc = cov * rcp_t<LEAN>(den, ok);
-                        if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
-                    }
-                };
+            };
+            {
                 bool ok = true;
                 vote_stage(std::true_type{}, ok);
                 if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
@@ -810,14 +844,7 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
 {
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
-    if (a.presampled) {
-        if (!a.samples) return hipErrorInvalidValue;
-        if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE, true>), grid, block, 0, st, a);
-        else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1, true>), grid, block, 0, st, a);
-        return hipGetLastError();
-    }
-    constexpr unsigned XL = StepLds<K, S>::EXTRA;
+    constexpr unsigned XL = AMVS_FAST_STEP_EXTRA_LDS;
     if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, XL, st, a);
     else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, XL, st, a);
     else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, XL, st, a);
@@ -837,7 +864,7 @@ static int step_fast_occupancy_ks()
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB,
-                                                                StepLds<K, S>::EXTRA);
+                                                                AMVS_FAST_STEP_EXTRA_LDS);
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
@@ -873,37 +900,6 @@ hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
     case 7: AMVS_FOR_S(7, launch_step_fast_ks, a, nblk, st)
     case 9: AMVS_FOR_S(9, launch_step_fast_ks, a, nblk, st)
     case 11: AMVS_FOR_S(11, launch_step_fast_ks, a, nblk, st)
-    default: return hipErrorInvalidValue;
-    }
-}
-
-// Resident workgroups of the sampling kernel per CU when it runs alone, through unused dynamic LDS;
-// the remainder of the 160 KiB is what the window kernel of another view group can take beside it.
-#ifndef AMVS_SAMPLE_LDS_BYTES
-#define AMVS_SAMPLE_LDS_BYTES (27 * 1024)
-#endif
-
-template <int S>
-static hipError_t launch_sample_fast_s(const StepArgs &a, hipStream_t st)
-{
-    const int nblk = a.n_jobs * a.s_tiles_x * a.s_tiles_y;
-    const dim3 grid((nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES), block(AMVS_WAVE * AMVS_WG_WAVES);
-    const unsigned XL = a.s_lds > 0 ? (unsigned)a.s_lds : (unsigned)AMVS_SAMPLE_LDS_BYTES;
-    if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_sample_fast_kernel<S, MODE_REFINE>), grid, block, XL, st, a);
-    else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_sample_fast_kernel<S, MODE_PROP>), grid, block, XL, st, a);
-    else hipLaunchKernelGGL((pm_sample_fast_kernel<S, -1>), grid, block, XL, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st)
-{
-    if (!a.pairs || !a.samples || a.s_TH < 1) return hipErrorInvalidValue;
-    switch (S) {
-    case 2: return launch_sample_fast_s<2>(a, st);
-    case 3: return launch_sample_fast_s<3>(a, st);
-    case 4: return launch_sample_fast_s<4>(a, st);
-    case 5: return launch_sample_fast_s<5>(a, st);
-    case 6: return launch_sample_fast_s<6>(a, st);
     default: return hipErrorInvalidValue;
     }
 }
