@@ -45,8 +45,9 @@ struct amvs_ctx {
     // exactly code/255 (n_inexact == 0); otherwise the sweep samples the float32 maps
     uint16_t *d_pairs = nullptr;
     long long pstride = 0;              // ushorts between packed maps
-    int *d_flag = nullptr;
-    std::vector<char> exact8;
+    int *d_flag = nullptr;               // [n_views] 1 = the view did not quantise to 8 bits losslessly
+    mutable std::vector<char> exact8;    // host copy of !d_flag, refreshed lazily (flags_dirty)
+    mutable bool flags_dirty = false;
     bool force_f32 = false;             // amvs_set_sampling: A/B switch for tests
     int mode = AMVS_MODE_EXACT;         // arithmetic of the sweeps (amvs_set_mode)
     int default_band_major = 0;         // schedule of amvs_pm_params.schedule == 0 (view-major measured faster)
@@ -247,6 +248,17 @@ int upload_jobs(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, 
 const uint16_t *usable_pairs(const amvs_ctx *c)
 {
     if (c->force_f32) return nullptr;
+    if (c->flags_dirty) {
+        // the uploads only queue the losslessness test; its results are read here, once
+        std::vector<int> flags(c->n_views, 1);
+        if (hipMemcpyAsync(flags.data(), c->d_flag, sizeof(int) * c->n_views, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            hipStreamSynchronize(c->stream) == hipSuccess) {
+            for (int v = 0; v < c->n_views; ++v) c->exact8[v] = flags[v] ? 0 : 1;
+            c->flags_dirty = false;
+        } else {
+            return nullptr;
+        }
+    }
     for (int v = 0; v < c->n_views; ++v)
         if (c->have[v] && !c->exact8[v]) return nullptr;
     return c->d_pairs;
@@ -454,7 +466,7 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
         a.mode = amvs::MODE_CONF;
         set_io(a, c, cur, cur_n);
-        a.aux = (float *)conf_dev;
+        a.aux = conf_dev ? (float *)conf_dev : c->d_aux;
         HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
     }
@@ -566,7 +578,7 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     // _compute_confidence (mvs_patchmatch.py:493-534): one fused launch over the whole batch
     all.mode = amvs::MODE_CONF;
     set_io(all, c, cur, cur_n);
-    all.aux = (float *)conf_dev;
+    all.aux = conf_dev ? (float *)conf_dev : c->d_aux;
     HIPCHK(c, amvs::launch_step(p->patch_size, n_src, all, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_groups[2], c->stream));
     c->timing.sweep_launches = (int64_t)sched.size();     // one hypothesis of the whole batch each
@@ -673,7 +685,8 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
         return bail("hipMalloc(pairs)", e);
     if ((e = hipMemsetAsync(c->d_pairs, 0, sizeof(uint16_t) * c->pstride * n_views, c->stream)) != hipSuccess)
         return bail("hipMemset(pairs)", e);
-    if ((e = hipMalloc(&c->d_flag, sizeof(int))) != hipSuccess) return bail("hipMalloc(flag)", e);
+    if ((e = hipMalloc(&c->d_flag, sizeof(int) * n_views)) != hipSuccess) return bail("hipMalloc(flag)", e);
+    if ((e = hipMemsetAsync(c->d_flag, 0, sizeof(int) * n_views, c->stream)) != hipSuccess) return bail("hipMemset(flag)", e);
     *out = c;
     return AMVS_OK;
 }
@@ -744,14 +757,13 @@ static int set_view_common(amvs_ctx *c, int view, const void *gray, const float 
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_images + view * c->stride, gray, sizeof(float) * c->H * c->W, kind,
                              c->stream));
-    // packed 8-bit map + losslessness test of this view
-    int inexact = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    // packed 8-bit map + losslessness test of this view (read back lazily, usable_pairs)
+    HIPCHK(c, hipMemsetAsync(c->d_flag + view, 0, sizeof(int), c->stream));
     HIPCHK(c, amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W,
-                                      c->d_pairs + view * c->pstride, c->d_flag, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&inexact, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->exact8[view] = inexact ? 0 : 1;
+                                      c->d_pairs + view * c->pstride, c->d_flag + view, c->stream));
+    c->flags_dirty = true;
+    // a host buffer is the caller's again on return; a device buffer is only ordered on the stream
+    if (kind == hipMemcpyHostToDevice) HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(c->R[view].data(), R, 36);
     std::memcpy(c->t[view].data(), t, 12);
     c->have[view] = 1;
@@ -817,16 +829,14 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
                                    c->d_images + view * c->stride, c->stream);
     if (e == hipSuccess && scaled_bgr_out)
         e = hipMemcpyAsync(scaled_bgr_out, d_scaled, 3 * n_dst, hipMemcpyDeviceToHost, c->stream);
-    int inexact = 0;
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_flag + view, 0, sizeof(int), c->stream);
     if (e == hipSuccess)
-        e = amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W, c->d_pairs + view * c->pstride, c->d_flag,
-                                    c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&inexact, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        e = amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W, c->d_pairs + view * c->pstride,
+                                    c->d_flag + view, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("set_view_bgr8: ") + hipGetErrorString(e));
-    c->exact8[view] = inexact ? 0 : 1;
+    c->flags_dirty = true;
     std::memcpy(c->R[view].data(), R, 36);
     std::memcpy(c->t[view].data(), t, 12);
     c->have[view] = 1;
@@ -845,12 +855,12 @@ int amvs_set_view_device(amvs_ctx *c, int view, const void *gray_device, const f
     return set_view_common(c, view, gray_device, R, t, hipMemcpyDeviceToDevice);
 }
 
-int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
-                           const amvs_pm_params *p, uint64_t seed, void *depth_dev, void *normal_dev,
-                           void *conf_dev)
+// The sweep of a batch: state in the context's buffers (final depth in d_depth[*cur], normals in
+// d_normal[*cur_n]), confidence into `conf_dev` (NULL: the context's d_aux).
+static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                           const amvs_pm_params *p, uint64_t seed, void *conf_dev, int *cur_out, int *cur_n_out)
 {
-    if (!c) return AMVS_EINVAL;
-    if (!p || !depth_dev || !normal_dev || !conf_dev) return fail(c, AMVS_EINVAL, "NULL argument");
+    if (!p || !ref_ids || !src_ids || n_ref <= 0) return fail(c, AMVS_EINVAL, "NULL argument / empty batch");
     if (p->num_iterations < 0 || p->num_samples < 0) return fail(c, AMVS_EINVAL, "negative iteration count");
     int rc = bind_device(c);
     if (rc) return rc;
@@ -876,45 +886,47 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
         if ((rc = run_fused_schedule(c, n_ref, n_src, p, seed, fast, sched, conf_dev))) return rc;
     }
     // every group ran the same schedule, so the final buffers (cur, cur_n) are the same for all
-    HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    *cur_out = cur; *cur_n_out = cur_n;
     c->timing.pixel_hypotheses =
         (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
     c->timing_pending = true;
     return AMVS_OK;
 }
 
+int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                           const amvs_pm_params *p, uint64_t seed, void *depth_dev, void *normal_dev,
+                           void *conf_dev)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!depth_dev || !normal_dev || !conf_dev) return fail(c, AMVS_EINVAL, "NULL output");
+    int cur = 0, cur_n = 0;
+    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, conf_dev, &cur, &cur_n);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    return AMVS_OK;
+}
+
+// Host-buffer entry: the maps go from the context's own state buffers straight to the caller's
+// arrays -- no per-call device allocation, one synchronisation.
 int amvs_patchmatch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
                     const amvs_pm_params *p, uint64_t seed, float *depth_out, float *normal_out,
                     float *conf_out)
 {
     if (!c) return AMVS_EINVAL;
     if (!depth_out || !normal_out || !conf_out || n_ref <= 0) return fail(c, AMVS_EINVAL, "NULL output");
-    int rc = bind_device(c);
+    int cur = 0, cur_n = 0;
+    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, nullptr, &cur, &cur_n);
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
-    float *dd = nullptr, *dn = nullptr, *dc = nullptr;
-    HIPCHK(c, hipMalloc(&dd, 4 * hw * n_ref));
-    hipError_t e1 = hipMalloc(&dn, 12 * hw * n_ref), e2 = hipMalloc(&dc, 4 * hw * n_ref);
-    if (e1 == hipSuccess && e2 == hipSuccess) {
-        rc = amvs_patchmatch_device(c, n_ref, ref_ids, src_ids, n_src, p, seed, dd, dn, dc);
-        if (rc == AMVS_OK) {
-            hipError_t e = hipMemcpyAsync(depth_out, dd, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(normal_out, dn, 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(conf_out, dc, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) rc = fail(c, AMVS_EHIP, std::string("download: ") + hipGetErrorString(e));
-            resolve_timing(c);
-        }
-    } else {
-        rc = fail(c, AMVS_EHIP, "hipMalloc(outputs) failed");
-    }
-    (void)hipStreamSynchronize(c->stream);
-    if (dd) (void)hipFree(dd);
-    if (dn) (void)hipFree(dn);
-    if (dc) (void)hipFree(dc);
-    return rc;
+    HIPCHK(c, hipMemcpyAsync(depth_out, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal_out, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timing(c);
+    return AMVS_OK;
 }
 
 int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
