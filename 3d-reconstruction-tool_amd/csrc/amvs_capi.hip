@@ -1220,6 +1220,7 @@ static int xpm_begin(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_
     a = amvs::XArgs{};
     a.H = c->H; a.W = c->W; a.n_jobs = n_ref; a.n_src = n_src;
     a.jobs = c->d_jobs; a.images = c->d_images; a.img_stride = c->stride;
+    a.pairs = usable_pairs(c); a.pair_stride = c->pstride;
     a.depth = (float *)depth_all; a.normal = (float *)normal_all; a.cost = (float *)cost_all;
     a.cand_d = c->d_xcand_d; a.cand_n = c->d_xcand_n; a.src_view = c->d_xsrc;
     a.patch = p->patch_size; a.stride = p->window_stride;

@@ -42,6 +42,27 @@ AMVS_DEV float xbilinear(const float *img, int H, int W, float u, float v, bool 
     return __builtin_fmaf(fy, bot - top, top);
 }
 
+// ascending list of per-source costs in registers (constant indices only: no scratch memory)
+AMVS_DEV void xsorted_insert(float (&costs)[AMVS_KMAX_SRC], float c)
+{
+#pragma unroll
+    for (int j = 0; j < AMVS_KMAX_SRC; ++j) {
+        const float lo = __builtin_fminf(costs[j], c), hi = __builtin_fmaxf(costs[j], c);
+        costs[j] = lo; c = hi;
+    }
+}
+
+// mean of the better half of the valid sources (at least two), +inf with fewer than two
+AMVS_DEV float xbetter_half(const float (&costs)[AMVS_KMAX_SRC], int n_valid)
+{
+    if (n_valid < 2) return __builtin_inff();
+    const int keep = (n_valid + 1) / 2 > 2 ? (n_valid + 1) / 2 : 2;
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < AMVS_KMAX_SRC; ++j) tot += j < keep ? costs[j] : 0.0f;
+    return tot / (float)keep;
+}
+
 // cost of hypothesis (d, n) at pixel (x, y) of the job's reference view
 AMVS_DEV float xcost(const XArgs &a, JobCP job, const float *ref, int x, int y, float d, float nx, float ny, float nz)
 {
@@ -55,6 +76,8 @@ AMVS_DEV float xcost(const XArgs &a, JobCP job, const float *ref, int x, int y, 
     const float delta = d * ndr_p;                            // plane: n.X = delta
     if (!(ndr_p < -1e-6f)) return __builtin_inff();           // plane must face the camera
     float costs[AMVS_KMAX_SRC];
+#pragma unroll
+    for (int j = 0; j < AMVS_KMAX_SRC; ++j) costs[j] = __builtin_inff();
     int n_valid = 0;
     for (int s = 0; s < a.n_src; ++s) {
         const CF M = job->fsrc[s].M, b = job->fsrc[s].b;
@@ -92,17 +115,147 @@ AMVS_DEV float xcost(const XArgs &a, JobCP job, const float *ref, int x, int y, 
         const float cov = srv - sr * sv * inv, vr = srr - sr * sr * inv, vs = svv - sv * sv * inv;
         const float den = vr * vs;
         const float ncc = den > 1e-12f ? cov / __builtin_sqrtf(den) : 0.0f;
-        // insertion into the ascending list of costs
-        float c = 1.0f - ncc;
-        int j = n_valid++;
-        while (j > 0 && costs[j - 1] > c) { costs[j] = costs[j - 1]; --j; }
-        costs[j] = c;
+        xsorted_insert(costs, 1.0f - ncc);
+        ++n_valid;
     }
-    if (n_valid < 2) return __builtin_inff();
-    const int keep = (n_valid + 1) / 2 > 2 ? (n_valid + 1) / 2 : 2;     // the better half, at least two
-    float tot = 0.f;
-    for (int j = 0; j < keep; ++j) tot += costs[j];
-    return tot / (float)keep;
+    return xbetter_half(costs, n_valid);
+}
+
+// ---- the same cost for the common window shapes, N x N taps (patch = (N-1) stride + 1) ----
+// Per pixel, once: the N*N reference taps and their sums.  Per hypothesis and source: the plane-induced
+// homography  [uz', vz', z'] = (delta M + b (n^T K^-1)) q  (the common factor 1 / n.K^-1 q of the
+// lifted point cancels in u = uz'/z'), advanced incrementally along a window row.  Every validity
+// condition of xcost -- the plane faces the camera along the tap's ray, the lifted point is in front of
+// the source, the footprint lies inside the source image -- is affine or projective in q, so it holds
+// on the whole window iff it holds at its four corners: the taps run without tests.
+template <int N> struct XRef {
+    float r[N * N];
+    float sr, srr;
+    bool inside;
+};
+
+template <int N>
+AMVS_DEV XRef<N> xref_load(const XArgs &a, const float *ref, int x, int y)
+{
+    XRef<N> R;
+    const int half = a.patch / 2, st = a.stride;
+    R.inside = (x - half >= 0) & (y - half >= 0) & (x - half + (N - 1) * st < a.W) & (y - half + (N - 1) * st < a.H);
+    R.sr = 0.f; R.srr = 0.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float v = R.inside ? ref[(long long)(y - half + j * st) * a.W + (x - half + i * st)] : 0.0f;
+            R.r[j * N + i] = v;
+            R.sr += v;
+            R.srr = __builtin_fmaf(v, v, R.srr);
+        }
+    return R;
+}
+
+// U8: the sources are sampled from the packed 8-bit row-pair maps (one dword per 2 x 2 footprint,
+// amvs_device.h) instead of four float loads; the sums run in code units and are rescaled once.
+template <int N, bool U8>
+AMVS_DEV float xcost_t(const XArgs &a, JobCP job, const XRef<N> &R, int x, int y, float rpx, float rpy, float d,
+                       float nx, float ny, float nz)
+{
+    if (!R.inside) return __builtin_inff();
+    const float ndr_p = __builtin_fmaf(nx, rpx, __builtin_fmaf(ny, rpy, nz));
+    if (!(ndr_p < -1e-6f)) return __builtin_inff();           // plane must face the camera
+    const float delta = d * ndr_p;                            // plane: n.X = delta
+    const float k0 = job->Kinv[0], k1 = job->Kinv[1], k2 = job->Kinv[2], k3 = job->Kinv[3], k4 = job->Kinv[4],
+                k5 = job->Kinv[5];
+    // n . K^-1 q = w . [qx, qy, 1]
+    const float w0 = __builtin_fmaf(ny, k3, nx * k0), w1 = __builtin_fmaf(ny, k4, nx * k1);
+    const float w2 = __builtin_fmaf(ny, k5, __builtin_fmaf(nx, k2, nz));
+    const float st = (float)a.stride;
+    const float x0 = (float)(x - a.patch / 2), y0 = (float)(y - a.patch / 2);
+    const float cx[2] = {x0, x0 + (float)(N - 1) * st}, cy[2] = {y0, y0 + (float)(N - 1) * st};
+    float ndr_c[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ndr_c[c] = __builtin_fmaf(w0, cx[c & 1], __builtin_fmaf(w1, cy[c >> 1], w2));
+    if (!(__builtin_fmaxf(__builtin_fmaxf(ndr_c[0], ndr_c[1]), __builtin_fmaxf(ndr_c[2], ndr_c[3])) < -1e-6f))
+        return __builtin_inff();                               // (the generic path skips every source then)
+    const float fw = (float)(a.W - 1), fh = (float)(a.H - 1);
+    constexpr float INV = 1.0f / (float)(N * N);
+    const float vr = R.srr - R.sr * R.sr * INV;
+    float costs[AMVS_KMAX_SRC];
+#pragma unroll
+    for (int j = 0; j < AMVS_KMAX_SRC; ++j) costs[j] = __builtin_inff();
+    int n_valid = 0;
+    for (int s = 0; s < a.n_src; ++s) {
+        const CF M = job->fsrc[s].M, b = job->fsrc[s].b;
+        const int sview = a.src_view[job->slot * a.n_src + s];
+        const float *img = a.images + (long long)sview * a.img_stride;
+        const unsigned long long pimg = (unsigned long long)(a.pairs + (U8 ? (long long)sview * a.pair_stride : 0ll));
+        constexpr int PB = AMVS_PAIR_BORDER;
+        const int ppitch = a.W + 2 * PB;
+        float Hm[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Hm[3 * r] = __builtin_fmaf(b[r], w0, delta * M[3 * r]);
+            Hm[3 * r + 1] = __builtin_fmaf(b[r], w1, delta * M[3 * r + 1]);
+            Hm[3 * r + 2] = __builtin_fmaf(b[r], w2, delta * M[3 * r + 2]);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float qx = cx[c & 1], qy = cy[c >> 1];
+            const float p0 = __builtin_fmaf(Hm[0], qx, __builtin_fmaf(Hm[1], qy, Hm[2]));
+            const float p1 = __builtin_fmaf(Hm[3], qx, __builtin_fmaf(Hm[4], qy, Hm[5]));
+            const float p2 = __builtin_fmaf(Hm[6], qx, __builtin_fmaf(Hm[7], qy, Hm[8]));
+            // depth in the source p2 / ndr > 0.1 with ndr < 0
+            ok &= p2 < 0.1f * ndr_c[c];
+            const float rz = 1.0f / p2;
+            const float u = p0 * rz, v = p1 * rz;
+            ok &= (u >= 0.0f) & (v >= 0.0f) & (u < fw) & (v < fh);
+        }
+        if (!ok) continue;
+        float sv = 0.f, svv = 0.f, srv = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float qy = y0 + (float)j * st;
+            float p0 = __builtin_fmaf(Hm[0], x0, __builtin_fmaf(Hm[1], qy, Hm[2]));
+            float p1 = __builtin_fmaf(Hm[3], x0, __builtin_fmaf(Hm[4], qy, Hm[5]));
+            float p2 = __builtin_fmaf(Hm[6], x0, __builtin_fmaf(Hm[7], qy, Hm[8]));
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float rz = __builtin_amdgcn_rcpf(p2);
+                const float u = p0 * rz, v = p1 * rz;
+                const float x0f = __builtin_floorf(u), y0f = __builtin_floorf(v);
+                // (corner test + convexity: 0 <= x0f <= W-2; the clamp only guards rounding at the rim)
+                const int xi = min(max((int)x0f, 0), a.W - 2), yi = min(max((int)y0f, 0), a.H - 2);
+                const float fx = u - x0f, fy = v - y0f;
+                float top, bot;
+                if constexpr (U8) {
+                    const uint32_t wd = load_pair_word(pimg, (yi + PB) * ppitch + xi + PB, 0);
+                    // bytes: (y,x) (y+1,x) (y,x+1) (y+1,x+1)
+                    const float t00 = (float)(wd & 0xFFu), t10 = (float)((wd >> 8) & 0xFFu);
+                    const float t01 = (float)((wd >> 16) & 0xFFu), t11 = (float)(wd >> 24);
+                    top = __builtin_fmaf(fx, t01 - t00, t00);
+                    bot = __builtin_fmaf(fx, t11 - t10, t10);
+                } else {
+                    const float *pp = img + (long long)yi * a.W + xi;
+                    top = __builtin_fmaf(fx, pp[1] - pp[0], pp[0]);
+                    bot = __builtin_fmaf(fx, pp[a.W + 1] - pp[a.W], pp[a.W]);
+                }
+                const float sval = __builtin_fmaf(fy, bot - top, top);
+                sv += sval;
+                svv = __builtin_fmaf(sval, sval, svv);
+                srv = __builtin_fmaf(R.r[j * N + i], sval, srv);
+                p0 = __builtin_fmaf(st, Hm[0], p0);
+                p1 = __builtin_fmaf(st, Hm[3], p1);
+                p2 = __builtin_fmaf(st, Hm[6], p2);
+            }
+        }
+        if constexpr (U8) { sv *= (1.0f / 255.0f); srv *= (1.0f / 255.0f); svv *= (1.0f / 65025.0f); }
+        const float cov = srv - R.sr * sv * INV, vs = svv - sv * sv * INV;
+        const float den = vr * vs;
+        const float ncc = den > 1e-12f ? cov * __builtin_amdgcn_rsqf(den) : 0.0f;
+        xsorted_insert(costs, 1.0f - ncc);
+        ++n_valid;
+    }
+    return xbetter_half(costs, n_valid);
 }
 
 AMVS_DEV void xnormalise_facing(float &nx, float &ny, float &nz)
@@ -186,6 +339,7 @@ __global__ __launch_bounds__(256) void xpm_view_candidates_kernel(const XArgs a)
 
 // one red-black half sweep: spatial propagation from the four neighbours of the other colour, the
 // view candidate, refinement; in place
+template <int NT, bool U8>
 __global__ __launch_bounds__(128) void xpm_sweep_kernel(const XArgs a)
 {
     const JobCP job = (JobCP)(a.jobs + blockIdx.y);
@@ -204,52 +358,68 @@ __global__ __launch_bounds__(128) void xpm_sweep_kernel(const XArgs a)
         const long long i = (long long)y * W + x;
         float bd = D[i], bnx = N[3 * i], bny = N[3 * i + 1], bnz = N[3 * i + 2];
         float bc = C[i];
-        if (!(bc < __builtin_inff())) bc = xcost(a, job, ref, x, y, bd, bnx, bny, bnz);
         const float rpx = __builtin_fmaf(Ki[1], (float)y, __builtin_fmaf(Ki[0], (float)x, Ki[2]));
         const float rpy = __builtin_fmaf(Ki[4], (float)y, __builtin_fmaf(Ki[3], (float)x, Ki[5]));
-        auto consider = [&](float d, float nx, float ny, float nz) {
-            if (!(d >= a.depth_min) || !(d <= a.depth_max)) return;
-            const float c = xcost(a, job, ref, x, y, d, nx, ny, nz);
-            if (c < bc) { bc = c; bd = d; bnx = nx; bny = ny; bnz = nz; }
-        };
-        // spatial propagation: the neighbour's plane extended to this pixel's ray
-        const int ox[4] = {-1, 1, 0, 0}, oy[4] = {0, 0, -1, 1};
-        for (int k = 0; k < 4; ++k) {
-            const int xx = x + ox[k], yy = y + oy[k];
-            if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H) continue;
-            const long long j = (long long)yy * W + xx;
-            const float nd = D[j], nx = N[3 * j], ny = N[3 * j + 1], nz = N[3 * j + 2];
-            const float rqx = __builtin_fmaf(Ki[1], (float)yy, __builtin_fmaf(Ki[0], (float)xx, Ki[2]));
-            const float rqy = __builtin_fmaf(Ki[4], (float)yy, __builtin_fmaf(Ki[3], (float)xx, Ki[5]));
-            const float dl = nd * (nx * rqx + ny * rqy + nz);
-            const float ndr = nx * rpx + ny * rpy + nz;
-            if (ndr < -1e-6f) consider(dl / ndr, nx, ny, nz);
-        }
-        if (a.with_view_cand) {
-            const float cd = a.cand_d[cbase + i];
-            if (cd > 0.0f) consider(cd, a.cand_n[3 * (cbase + i)], a.cand_n[3 * (cbase + i) + 1], a.cand_n[3 * (cbase + i) + 2]);
-        }
-        // refinement
-        for (int r = 0; r < a.n_refine; ++r) {
-            const StreamKey key = stream_key(a.seed, job->stream_view, a.draw * 8u + (unsigned)r);
-            const uint32_t h0 = pixel_hash((uint32_t)i, key);
-            float g0, g1, g2;
-            rng_normals3(h0, g0, g1, g2);
-            const float scale = r == 0 ? 1.0f : 0.25f;          // a wide and a narrow perturbation
-            float d = bd * (1.0f + (rng_uniform(h0) * 2.0f - 1.0f) * a.rel_range * scale);
-            float nx = bnx + g0 * a.nrm_range * scale, ny = bny + g1 * a.nrm_range * scale, nz = bnz + g2 * a.nrm_range * scale;
-            xnormalise_facing(nx, ny, nz);
-            consider(d, nx, ny, nz);
-        }
-        if (a.with_random) {
-            const StreamKey key = stream_key(a.seed, job->stream_view, a.draw * 8u + 7u);
-            const uint32_t h0 = pixel_hash((uint32_t)i, key);
-            float g0, g1, g2;
-            rng_normals3(h0, g0, g1, g2);
-            const float lmin = __builtin_logf(a.depth_min), lmax = __builtin_logf(a.depth_max);
-            float nx = g0 * 0.3f, ny = g1 * 0.3f, nz = -1.0f;
-            xnormalise_facing(nx, ny, nz);
-            consider(__builtin_expf(lmin + rng_uniform(h0) * (lmax - lmin)), nx, ny, nz);
+        constexpr int NR = NT > 0 ? NT : 1;
+        const XRef<NR> R = NT > 0 ? xref_load<NR>(a, ref, x, y) : XRef<NR>{};
+        // Hypotheses in order: 0 the current plane (only while its cost is unknown), 1-4 the planes of the
+        // four neighbours of the other colour extended to this pixel's ray, 5 the view candidate,
+        // 6.. the refinements of the best so far, last a fresh random plane.  ONE call site of the cost
+        // (the window loops are unrolled: inlining it per hypothesis cost 230 VGPRs and scratch memory).
+        const int n_hyp = 6 + a.n_refine + (a.with_random ? 1 : 0);
+        for (int hyp = 0; hyp < n_hyp; ++hyp) {
+            float d = bd, nx = bnx, ny = bny, nz = bnz;
+            bool have = true;
+            if (hyp == 0) {
+                have = !(bc < __builtin_inff());
+            } else if (hyp <= 4) {
+                const int k = hyp - 1;
+                const int xx = x + (k == 0 ? -1 : (k == 1 ? 1 : 0)), yy = y + (k == 2 ? -1 : (k == 3 ? 1 : 0));
+                have = ((unsigned)xx < (unsigned)W) & ((unsigned)yy < (unsigned)H);
+                if (have) {
+                    const long long j = (long long)yy * W + xx;
+                    const float nd = D[j];
+                    nx = N[3 * j]; ny = N[3 * j + 1]; nz = N[3 * j + 2];
+                    const float rqx = __builtin_fmaf(Ki[1], (float)yy, __builtin_fmaf(Ki[0], (float)xx, Ki[2]));
+                    const float rqy = __builtin_fmaf(Ki[4], (float)yy, __builtin_fmaf(Ki[3], (float)xx, Ki[5]));
+                    const float dl = nd * (nx * rqx + ny * rqy + nz);
+                    const float ndr = nx * rpx + ny * rpy + nz;
+                    have = ndr < -1e-6f;
+                    d = dl / ndr;
+                }
+            } else if (hyp == 5) {
+                have = a.with_view_cand != 0;
+                if (have) {
+                    d = a.cand_d[cbase + i];
+                    have = d > 0.0f;
+                    nx = a.cand_n[3 * (cbase + i)]; ny = a.cand_n[3 * (cbase + i) + 1]; nz = a.cand_n[3 * (cbase + i) + 2];
+                }
+            } else if (hyp < 6 + a.n_refine) {
+                const int r = hyp - 6;
+                const StreamKey key = stream_key(a.seed, job->stream_view, a.draw * 8u + (unsigned)r);
+                const uint32_t h0 = pixel_hash((uint32_t)i, key);
+                float g0, g1, g2;
+                rng_normals3(h0, g0, g1, g2);
+                const float scale = r == 0 ? 1.0f : 0.25f;          // a wide and a narrow perturbation
+                d = bd * (1.0f + (rng_uniform(h0) * 2.0f - 1.0f) * a.rel_range * scale);
+                nx = bnx + g0 * a.nrm_range * scale; ny = bny + g1 * a.nrm_range * scale; nz = bnz + g2 * a.nrm_range * scale;
+                xnormalise_facing(nx, ny, nz);
+            } else {
+                const StreamKey key = stream_key(a.seed, job->stream_view, a.draw * 8u + 7u);
+                const uint32_t h0 = pixel_hash((uint32_t)i, key);
+                float g0, g1, g2;
+                rng_normals3(h0, g0, g1, g2);
+                const float lmin = __builtin_logf(a.depth_min), lmax = __builtin_logf(a.depth_max);
+                nx = g0 * 0.3f; ny = g1 * 0.3f; nz = -1.0f;
+                xnormalise_facing(nx, ny, nz);
+                d = __builtin_expf(lmin + rng_uniform(h0) * (lmax - lmin));
+            }
+            if (hyp > 0) have = have & (d >= a.depth_min) & (d <= a.depth_max);
+            if (!have) continue;
+            float c;
+            if constexpr (NT > 0) c = xcost_t<NT, U8>(a, job, R, x, y, rpx, rpy, d, nx, ny, nz);
+            else c = xcost(a, job, ref, x, y, d, nx, ny, nz);
+            if (hyp == 0 || c < bc) { bc = c; bd = d; bnx = nx; bny = ny; bnz = nz; }
         }
         D[i] = bd; N[3 * i] = bnx; N[3 * i + 1] = bny; N[3 * i + 2] = bnz; C[i] = bc;
     }
@@ -319,7 +489,23 @@ hipError_t launch_xpm_view_candidates(const XArgs &a, hipStream_t st)
 
 hipError_t launch_xpm_sweep(const XArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(xpm_sweep_kernel, xgrid(((long long)a.H * a.W + 1) / 2, 128, a.n_jobs), dim3(128), 0, st, a);
+    const dim3 grid = xgrid(((long long)a.H * a.W + 1) / 2, 128, a.n_jobs), blk(128);
+    // taps per axis; the specialised cost needs patch = (N - 1) stride + 1 with 3 <= N <= 7
+    const int n = (a.patch - 1) / a.stride + 1;
+    const bool fits = (n - 1) * a.stride + 1 == a.patch;
+    const bool u8 = a.pairs != nullptr;
+#define AMVS_XSWEEP(NT_)                                                                                      \
+    if (u8) hipLaunchKernelGGL((xpm_sweep_kernel<NT_, true>), grid, blk, 0, st, a);                              \
+    else hipLaunchKernelGGL((xpm_sweep_kernel<NT_, false>), grid, blk, 0, st, a)
+    switch (fits ? n : 0) {
+    case 3: AMVS_XSWEEP(3); break;
+    case 4: AMVS_XSWEEP(4); break;
+    case 5: AMVS_XSWEEP(5); break;
+    case 6: AMVS_XSWEEP(6); break;
+    case 7: AMVS_XSWEEP(7); break;
+    default: hipLaunchKernelGGL((xpm_sweep_kernel<0, false>), grid, blk, 0, st, a); break;
+    }
+#undef AMVS_XSWEEP
     return hipGetLastError();
 }
 

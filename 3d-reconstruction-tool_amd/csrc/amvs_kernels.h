@@ -148,6 +148,8 @@ struct XArgs {
     const Job *jobs;
     const float *images;          // float32 gray maps [n_views][img_stride]
     long long img_stride;
+    const uint16_t *pairs;        // packed 8-bit row-pair maps [n_views][pair_stride] (NULL: sample `images`)
+    long long pair_stride;
     float *depth, *normal, *cost; // state of ALL views: [n_views][H*W] (normal x3), indexed by Job::ref_img
     float *cand_d, *cand_n;       // view-propagation candidates [n_jobs][H*W] (x3), indexed by Job::slot
     const int *src_view;          // [n_jobs][n_src] view ids of the sources
