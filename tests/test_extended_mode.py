@@ -123,3 +123,49 @@ def test_extended_mode_two_ranks_all_gather_between_iterations():
         assert p.exitcode == 0
     for rank, pts, cols in results:
         assert np.array_equal(pts, single_pts) and np.array_equal(cols, single_cols), f"rank {rank}"
+
+
+def _engine_level_run(patch, stride, force_f32, iters=3):
+    """The extended kernels through the Engine API on one small scene; returns the depth maps."""
+    import torch
+    import amvs
+    from amvs.engine import make_xpm_params
+    sc = _scene()
+    ids = sorted(sc.poses)
+    H, W = sc.depths[ids[0]].shape
+    grays = [np.round(sc.grays[i] * 255.0).clip(0, 255).astype(np.uint8).astype(np.float32) / np.float32(255.0) for i in ids]
+    dev = torch.device("cuda", 0)
+    with amvs.Engine(H, W, len(ids), sc.camera.K.astype(np.float32), mode="fast") as eng:
+        for n, i in enumerate(ids):
+            eng.set_view(n, grays[n], sc.poses[i].R, sc.poses[i].t)
+        eng.set_sampling(force_f32)
+        depth = torch.zeros((len(ids), H * W), dtype=torch.float32, device=dev)
+        normal = torch.zeros((len(ids), 3 * H * W), dtype=torch.float32, device=dev)
+        cost = torch.full((len(ids), H * W), float("inf"), dtype=torch.float32, device=dev)
+        refs = list(range(len(ids)))
+        srcs = [[j for j in sorted(refs, key=lambda j: abs(j - r)) if j != r][:4] for r in refs]
+        p = make_xpm_params(patch, sc.depth_min, sc.depth_max, window_stride=stride, num_refine=2)
+        ptrs = (depth.data_ptr(), normal.data_ptr(), cost.data_ptr())
+        torch.cuda.synchronize()
+        eng.xpm_init(refs, srcs, p, 11, *ptrs)
+        for it in range(iters):
+            eng.xpm_iterate(refs, srcs, p, it, 11, *ptrs)
+        eng.sync()
+        return sc, depth.cpu().numpy().reshape(len(ids), H, W)
+
+
+def test_extended_cost_paths_agree():
+    """The three implementations of the window cost -- packed 8-bit sampling, float sampling, and the
+    generic loop for window shapes that are not N x N taps -- converge on the same surface."""
+    sc, d_u8 = _engine_level_run(7, 2, False)
+    _, d_f32 = _engine_level_run(7, 2, True)
+    _, d_gen = _engine_level_run(9, 3, False)            # (9-1)/3 + 1 = 3 taps would span 7, not 9: generic loop
+    gt = sc.depths[3]
+    # (the generic run has 3 x 3 = 9 taps in a 9 x 9 window: a weaker cost, measured 0.80)
+    for name, d, least in (("u8", d_u8, 0.9), ("f32", d_f32, 0.9), ("generic", d_gen, 0.7)):
+        frac = _within(d[3], gt).mean()
+        assert frac > least, f"{name}: {frac:.3f} of the middle view within 1 % after 3 iterations"
+    # same arithmetic up to the rounding of the sampled values: the two specialised paths pick the same
+    # plane almost everywhere
+    close = np.abs(d_u8[3] - d_f32[3]) <= 1e-3 * d_f32[3]
+    assert close.mean() > 0.97, f"{close.mean():.3f}"
