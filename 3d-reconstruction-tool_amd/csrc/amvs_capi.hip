@@ -287,30 +287,37 @@ int default_views_per_launch(const amvs_ctx *c, int n_ref)
     return n_ref < 32 ? n_ref : 32;
 }
 
-// Rows per wave strip.  A strip re-samples 2*(patch/2) halo rows, so tall strips waste less, but
-// the launch needs several strips per resident wave slot to keep all CUs busy to the end.
-// Measured on MI355X (16 views 1080p, k=7): 16 rows 24.6, 32 rows 25.3-26.7, 64 rows 24.1-24.7,
-// 128 rows 20.0 G px-hyp/s -- so 32 rows when that yields >= 3 strips per slot, else shorter.
+// Rows per wave strip.  A strip re-samples 2*(patch/2) halo rows, so tall strips waste less; two
+// things pull the other way.  (1) The set of source rows the resident waves touch at once: measured
+// on MI355X (S=4, 16 views 1080p; best strip height per patch size) k=3: 10-12 rows, k=5: 14-18, k=7:
+// 20-26 (32: -3 %, 40+: -15 %), k=9: 24-32, k=11: 32-40, i.e. about 4k-4, and lower for wider images
+// (8 views 4K, k=7: 12-16 rows best, 24: -6 %) -- that is the cap `tall`.  (2) Wave quantisation: the
+// launch runs in generations of `slots` resident waves, and a last generation that is nearly empty
+// costs as much as a full one.  Measured, k=7, 1080p, G px-hyp/s by (views per launch: strip rows):
+// 16: 24 -> 40.2; 8: 24 / 20 / 16 / 12 -> 39.2 / 39.2 / 39.1 / 38.5; 4: 24 / 16 / 12 / 8 -> 36.7 / 38.4 /
+// 39.9 / 37.5; 2: 24 / 16 / 12 / 8 -> 39.4 / 34.5 / 38.6 / 35.9; 1: 24 / 16 / 12 / 8 -> 26.5 / 29.0 / 35.3 / 29.1
+// -- the winners are the heights whose wave count is just below a whole number of generations
+// (or at least 3/4 of one).  Hence: among the heights up to `tall`, the best product of the last
+// generation's fill and the strip's useful fraction rows / (rows + patch - 1).
 int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap, bool fast = false)
 {
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
     const long long slots = (long long)c->n_cu * (fast ? amvs::step_fast_waves_per_cu(patch, n_src)
                                                        : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr));
-    // measured on MI355X (S=4, 16 views 1080p; best strip height per patch size): k=3: 10-12 rows,
-    // k=5: 14-18, k=7: 20-26 (32: -3 %, 40+: -15 %), k=9: 24-32, k=11: 32-40, i.e. about 4k-4: smaller
-    // patches leave more waves resident, and what matters is the set of source rows the resident
-    // waves touch at once.  For the same reason wider images want lower strips (8 views 4K, k=7:
-    // 12-16 rows best, 24: -6 %).
     int tall = 4 * patch - 4 > 12 ? 4 * patch - 4 : 12;
     if (c->W > 2048) tall = tall * 2 / 3 > 8 ? tall * 2 / 3 : 8;
-    const int cands[3] = {tall, tall < 16 ? tall : 16, 8};
-    for (int th : cands) {
-        if (th > cap) continue;
-        const long long waves = (long long)n_jobs * tiles_x * ((c->H + th - 1) / th);
-        if (waves >= 3 * slots) return th;
+    if (tall > cap) tall = cap;
+    int best = tall < 8 ? tall : 8;
+    double best_score = -1.0;
+    for (int th = tall; th >= (tall < 8 ? tall : 8); th -= 2) {
+        const double waves = (double)n_jobs * tiles_x * ((c->H + th - 1) / th);
+        const double g = waves / (double)slots;
+        const double fill = g > 1.0 ? g / std::ceil(g) : (g >= 0.75 ? 1.0 : g / 0.75);
+        const double score = fill * (double)th / (double)(th + patch - 1);
+        if (score > best_score + 1e-9) { best_score = score; best = th; }
     }
-    return 8;
+    return best;
 }
 
 // Band-major schedule (StepArgs::band_major): strip height such that ONE band of all views of the
