@@ -38,11 +38,11 @@ typedef struct amvs_ctx amvs_ctx;
 
 /* Arithmetic of the sweep kernels (SURVEY.md section 8b proposed a `mode` parameter).
  *   AMVS_MODE_EXACT  every float32 operation of the reference's torch chain reproduced in order
- *                    (mvs_patchmatch.py:341-411): bit-identical to the CPU oracle's exact mode,
+ *                    (mvs_patchmatch.py:341-411): bit-identical to the exact mode of the tests' CPU checker,
  *                    which matches torch-CPU bit for bit up to the box filter's summation order.
  *   AMVS_MODE_FAST   the same algorithm with the projection precomposed per source, one
  *                    reciprocal per projection and 8-bit code arithmetic:
- *                    bit-identical to the CPU oracle's fast mode, which is pinned against the
+ *                    bit-identical to the fast mode of the tests' CPU checker, which is pinned against the
  *                    reference's golden vectors within the tolerances DESIGN.md states (cost
  *                    mean 2e-6; >= 98 % of depths within 1e-3 relative end to end).  Needs 8-bit
  *                    images (every view exactly code/255); otherwise the call fails with
@@ -283,7 +283,7 @@ int amvs_write_ply(const char *path, const double *points, const int64_t *colors
 /* Self test: the kernels replace the IEEE divide / sqrt expansions by v_rcp_f32 / v_rsq_f32 with
  * FMA corrections (plus an IEEE path for out-of-range operands).  Compares both against
  * 1.0f/x and sqrtf(x) on ALL 2^32 float bit patterns; mismatches[0] = reciprocal,
- * mismatches[1] = square root (both must be 0 for bit-exact parity with the CPU oracle).      */
+ * mismatches[1] = square root (both must be 0 for bit-exact parity with the tests' CPU checker).      */
 int amvs_selftest_lean_math(amvs_ctx *ctx, uint64_t mismatches[2]);
 
 #ifdef __cplusplus
