@@ -106,13 +106,28 @@ struct FastTap { float wx, wy; int off; };
 // footprint's dword, validity.  LEAN: v_rcp_f32 + one FMA correction == 1.0f / zz wherever
 // 2^-95 <= |zz| < 2^96 (amvs_device.h, verified exhaustively); the caller collects min / max |zz|
 // over the sources and repeats the row with LEAN = false if a lane left that range.
+// The column part of M [x, y, 1] -- fma(M0, x, M2), fma(M3, x, M5), fma(M6, x, M8) -- does not change
+// along a lane's column: the row loops compute it once per strip and source (fast_column_terms)
+// and pass it in; the operations and their order are those of the unhoisted form, so are the bits.
+struct FastCol { float t0, t1, t2; };
+
+template <class MP>
+AMVS_DEV FastCol fast_column_terms(MP M, float fx)
+{
+    FastCol c;
+    c.t0 = __builtin_fmaf(M[0], fx, M[2]);
+    c.t1 = __builtin_fmaf(M[3], fx, M[5]);
+    c.t2 = __builtin_fmaf(M[6], fx, M[8]);
+    return c;
+}
+
 template <bool LEAN, bool BOUNDED, class MP, class BP>
-AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, float fx, float fy, float d, bool &valid,
+AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, const FastCol &col, float fy, float d, bool &valid,
                            float &zlo, float &zhi)
 {
-    const float q0 = __builtin_fmaf(M[1], fy, __builtin_fmaf(M[0], fx, M[2]));
-    const float q1 = __builtin_fmaf(M[4], fy, __builtin_fmaf(M[3], fx, M[5]));
-    const float q2 = __builtin_fmaf(M[7], fy, __builtin_fmaf(M[6], fx, M[8]));
+    const float q0 = __builtin_fmaf(M[1], fy, col.t0);
+    const float q1 = __builtin_fmaf(M[4], fy, col.t1);
+    const float q2 = __builtin_fmaf(M[7], fy, col.t2);
     const float p0 = __builtin_fmaf(d, q0, b[0]);
     const float p1 = __builtin_fmaf(d, q1, b[1]);
     const float p2 = __builtin_fmaf(d, q2, b[2]);
@@ -166,9 +181,17 @@ AMVS_DEV float fast_finish(uint32_t w, const FastTap &t, bool live)
     return live ? v : 0.0f;
 }
 
+// the column terms of all S sources for a lane's column (once per strip)
+template <int S>
+AMVS_DEV void fast_columns(JobCP job, float fx, FastCol (&cols)[S])
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) cols[s] = fast_column_terms(job->fsrc[s].M, fx);
+}
+
 template <int S, bool LEAN, bool BOUNDED>
-AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, float fx, float fy, float d, bool live,
-                                      float (&v)[S], bool &ok)
+AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, const FastCol (&cols)[S], float fy, float d,
+                                      bool live, float (&v)[S], bool &ok)
 {
     unsigned okbits = 0u;
     FastTap tg[S];
@@ -179,13 +202,12 @@ AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, float fx,
     for (int s = 0; s < S; ++s) {
         if (s % AMVS_FAST_RELOAD_STRIDE == 0) jr = reload(jr);
         float M[9], b[3];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) M[i] = jr->fsrc[s].M[i];
+        M[1] = jr->fsrc[s].M[1]; M[4] = jr->fsrc[s].M[4]; M[7] = jr->fsrc[s].M[7];
 #pragma unroll
         for (int i = 0; i < 3; ++i) b[i] = jr->fsrc[s].b[i];
         const unsigned long long img = jr->fsrc[s].pairs;
         bool valid;
-        tg[s] = fast_geom<LEAN, BOUNDED>(M, b, fc, fx, fy, d, valid, zlo, zhi);
+        tg[s] = fast_geom<LEAN, BOUNDED>(M, b, fc, cols[s], fy, d, valid, zlo, zhi);
         okbits |= valid ? (1u << s) : 0u;
         raw[s] = fast_load(img, tg[s].off);
     }
@@ -197,13 +219,13 @@ AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, float fx,
 
 // optimistic lean reciprocals first, IEEE repeat if some lane's z left the verified range
 template <int S, bool BOUNDED>
-AMVS_DEV unsigned fast_sample_sources_checked(JobCP job, const FastConsts &fc, float fx, float fy, float d,
-                                              bool live, float (&v)[S])
+AMVS_DEV unsigned fast_sample_sources_checked(JobCP job, const FastConsts &fc, const FastCol (&cols)[S], float fy,
+                                              float d, bool live, float (&v)[S])
 {
     bool ok = true;
-    unsigned okbits = fast_sample_sources<S, true, BOUNDED>(job, fc, fx, fy, d, live, v, ok);
+    unsigned okbits = fast_sample_sources<S, true, BOUNDED>(job, fc, cols, fy, d, live, v, ok);
     if (__builtin_expect(!__all(ok), 0))
-        okbits = fast_sample_sources<S, false, BOUNDED>(reload(job), fc, fx, fy, d, live, v, ok);
+        okbits = fast_sample_sources<S, false, BOUNDED>(reload(job), fc, cols, fy, d, live, v, ok);
     return okbits;
 }
 
@@ -316,6 +338,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kern
     const int xr = tx * AMVS_WAVE + lane;
     const int y0 = ty * a.s_TH;
     const float fx = (float)xr;
+    FastCol cols[S];
+    fast_columns<S>(job, fx, cols);
     const bool col_in = xr < W;
     const int rows = min(a.s_TH, H - y0);
     const int oy = mode == MODE_PROP ? a.oy : 0, ox = mode == MODE_PROP ? a.ox : 0;
@@ -333,7 +357,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kern
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
         const float dc = candidate_depth(a, mode, inb, d_raw, h0);
         float v[S];
-        const unsigned okbits = fast_sample_sources_checked<S, true>(job, fc, fx, (float)yr, dc, live, v);
+        const unsigned okbits = fast_sample_sources_checked<S, true>(job, fc, cols, (float)yr, dc, live, v);
         if (live) {
 #pragma unroll
             for (int s = 0; s < S; ++s) out[s * HW + pix] = sample_encode(v[s], (okbits >> s) & 1u);
@@ -392,6 +416,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const int y0 = ty * a.TH;
     const int xr = xbase + lane;
     const float fx = (float)xr;
+    FastCol cols[S];
+    fast_columns<S>(job, fx, cols);
     const bool col_in = (unsigned)xr < (unsigned)W;
     const int rows = min(a.TH, H - y0) + 2 * HALF;
 
@@ -438,7 +464,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
             // ---- candidate depth of this (possibly halo) pixel: as in the exact kernel ----
             const float d_raw = d_in[inb ? pix + noff : 0];
             const float dc = candidate_depth(a, mode, inb, d_raw, h0);
-            okbits = fast_sample_sources_checked<S, true>(job, fc, fx, (float)yr, dc, live, v);
+            okbits = fast_sample_sources_checked<S, true>(job, fc, cols, (float)yr, dc, live, v);
         }
         const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
 
@@ -586,6 +612,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const int y0 = ty * a.TH;
     const int xr = xbase + lane;
     const float fx = (float)xr;
+    FastCol cols[S];
+    fast_columns<S>(job, fx, cols);
     const bool col_in = (unsigned)xr < (unsigned)W;
     const int trows = min(a.TH, H - y0);
     const int rows = trows + 2 * HALF;
@@ -612,7 +640,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
             const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
             float v[S];
-            const unsigned okbits = fast_sample_sources_checked<S, false>(job, fc, fx, (float)yr, depth, live, v);
+            const unsigned okbits = fast_sample_sources_checked<S, false>(job, fc, cols, (float)yr, depth, live, v);
             ref_bytes_push<K>(rb, rcode);
             fring_push<K, S>(lring, lane, wslot, ring_v, v);
             wslot = wslot + 1 == K ? 0 : wslot + 1;
@@ -697,8 +725,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void sample_dump_fast_kernel(const StepA
     const float d = a.d_in[live ? y * W + x : 0];
     float v[S];
     unsigned okbits;
-    if (a.mode == MODE_EVAL + 100) okbits = fast_sample_sources_checked<S, false>(job, fc, (float)x, (float)y, d, live, v);
-    else okbits = fast_sample_sources_checked<S, true>(job, fc, (float)x, (float)y, d, live, v);
+    FastCol cols[S];
+    fast_columns<S>(job, (float)x, cols);
+    if (a.mode == MODE_EVAL + 100) okbits = fast_sample_sources_checked<S, false>(job, fc, cols, (float)y, d, live, v);
+    else okbits = fast_sample_sources_checked<S, true>(job, fc, cols, (float)y, d, live, v);
     if (live) {
 #pragma unroll
         for (int s = 0; s < S; ++s) out[s * HW + y * W + x] = v[s];
