@@ -123,6 +123,7 @@ def main():
                          "0 = 1 on one GPU, 2 otherwise")
     ap.add_argument("--workload", choices=["patchmatch", "planesweep"], default="patchmatch")
     ap.add_argument("--planes", type=int, default=64)
+    ap.add_argument("--sweep-tile-rows", type=int, default=0, help="plane sweep: rows per strip (0 = automatic)")
     ap.add_argument("--mode", choices=["fast", "exact"], default="fast",
                     help="arithmetic of the sweep kernels (include/amvs.h AMVS_MODE_*)")
     ap.add_argument("--split-groups", type=int, default=0, help="split schedule: view groups (0 = automatic)")
@@ -428,6 +429,8 @@ def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
     eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=0, mode=args.mode)
     stream = torch.cuda.Stream(device=dev)
     eng.set_stream(stream.cuda_stream)
+    if getattr(args, "sweep_tile_rows", 0):
+        eng.set_sweep_tuning(args.sweep_tile_rows, 0)
     lut = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255.0)).to(dev)
     for i in ids:
         codes = torch.round(torch.from_numpy(sc.grays[i]).to(dev) * 255.0).clamp(0, 255).long()
