@@ -99,7 +99,10 @@ int amvs_set_stream(amvs_ctx *ctx, void *hip_stream);     /* NULL = context's ow
 int amvs_sync(amvs_ctx *ctx);
 
 /* Upload one view once per scene (the reference re-uploads every view for every
- * reference view, mvs_patchmatch.py:235-257).                                     */
+ * reference view, mvs_patchmatch.py:235-257).  amvs_set_view returns when the host buffer
+ * has been consumed.  amvs_set_view_device only ORDERS the copy on the context's stream: the
+ * device buffer must be complete before the call (as seen from that stream) and stay unchanged
+ * until the stream has passed it (amvs_sync, or any synchronising call).                        */
 int amvs_set_view(amvs_ctx *ctx, int view, const float *gray_host,
                   const float R[9], const float t[3]);
 int amvs_set_view_device(amvs_ctx *ctx, int view, const void *gray_device,
