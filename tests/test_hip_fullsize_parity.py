@@ -117,3 +117,30 @@ def test_config2_8x720p_plane_sweep_bit_exact(mode):
         _eq(dmap[r], od, f"{mode} 720p sweep view {r} depth")
         _eq(conf[r], oc, f"{mode} 720p sweep view {r} confidence")
     assert conf.max() >= 3
+
+
+def test_strip_height_follows_wave_quantisation(scene_1080):
+    """pick_tile_rows (csrc/amvs_capi.hip): the automatic strip height makes the wave count of a launch
+    land just below a whole number of generations of resident waves (256 CUs x 16 waves) -- 24 rows for
+    the 16-view launch the bench times, 18 for 4 views, 24 for 2, 12 for one -- and the maps do not
+    depend on it."""
+    import amvs
+    from amvs.engine import make_pm_params
+    sc = scene_1080
+    H, W = 1080, 1920
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = [pm._select_source_views(r, ids, sc.poses, k=4) for r in ids]
+    with amvs.Engine(H, W, 16, sc.camera.K.astype(np.float32), mode="fast") as eng:
+        for i in ids:
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        got = {}
+        maps = {}
+        for n in (16, 4, 2, 1):
+            p = make_pm_params(7, 1, 1, sc.depth_min, sc.depth_max, views_per_launch=n)
+            maps[n] = eng.patchmatch(ids[:4], sources[:4], p, 3)
+            got[n] = eng.last_tile_rows()
+    assert got == {16: 18, 4: 18, 2: 24, 1: 12}, got          # (a 4-view batch caps views_per_launch at 4)
+    for n in (4, 2, 1):
+        for a, b, what in zip(maps[16], maps[n], ("depth", "normal", "confidence")):
+            _eq(b, a, f"{what}, {n} views per launch")
