@@ -39,7 +39,8 @@ namespace {
 constexpr int KNN_KMAX = 32;
 constexpr int KNN_GMAX = 256;       // cells per axis (dense table of at most 2^24 cells)
 constexpr int KNN_SHELLS = 2;       // Chebyshev shells a query walks on one grid level
-constexpr int KNN_LEVELS = 3;       // grid levels (cell edge x2 per level) before the block scans
+constexpr int KNN_LEVELS = 10;      // cap on the grid levels (cell edge x2 per level); the block scans take
+                                    // over as soon as fewer than n / 64 queries are pending
 
 struct Grid {
     double lo[3];
@@ -530,7 +531,9 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
                          gr.g[0], gr.g[1], gr.g[2], ms, left, n);
         }
         if (whole_grid || left == 0 || level == KNN_LEVELS - 1) break;
-        // the next level only pays when many queries are left; a few thousand go straight to the scans
+        // the next level only pays when many queries are left; a few thousand go straight to the
+        // scans (one block per query, O(n) each) -- and ONLY a few thousand: a strongly non-uniform
+        // cloud keeps coarsening instead of scanning for a large share of its points
         if ((long long)left * 64 < n) break;
         h *= 2.0;
         double unused = -1.0;

@@ -472,6 +472,10 @@ def _knn_clouds():
     line[:, 0] = np.sort(rng.uniform(0, 1, 400))           # degenerate extents in y and z
     clouds["line"] = line
     clouds["volume float32 values"] = rng.uniform(-1, 1, (6000, 3)).astype(np.float32).astype(np.float64)
+    # strongly non-uniform: a tight cluster that sets the cell size and a wide halo a third of the
+    # points live in -- more grid levels than three are needed before few enough queries are left
+    # for the per-query scans
+    clouds["cluster+halo"] = np.vstack([rng.normal(0, 0.01, (20000, 3)), rng.uniform(-50.0, 50.0, (10000, 3))])
     return clouds
 
 
