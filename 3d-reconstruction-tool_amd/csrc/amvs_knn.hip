@@ -13,8 +13,9 @@
 // search here: points are binned into a uniform grid over the 1st-99th percentile box (counting
 // sort, cell edge h fitted to the occupancy); a thread per point visits the cells of Chebyshev shells
 // 0..2 around its own cell and is done after shell r once its k-th smallest squared distance is
-// <= (r*h)^2 (everything not yet visited is farther); queries left pending repeat on coarser grids
-// (edge x2), and the remainder -- isolated points -- is answered by one block each scanning all points.
+// <= (r*h)^2 (everything not yet visited is farther); a query left pending gets one block that scans
+// the box of cells within R = 4, 8, 16, ... shells cooperatively (knn_box_kernel) until the same rule
+// holds or the box is the whole grid.
 #include "amvs_kernels.h"
 
 #include <hipcub/hipcub.hpp>
@@ -39,8 +40,9 @@ namespace {
 constexpr int KNN_KMAX = 32;
 constexpr int KNN_GMAX = 256;       // cells per axis (dense table of at most 2^24 cells)
 constexpr int KNN_SHELLS = 2;       // Chebyshev shells a query walks on one grid level
-constexpr int KNN_LEVELS = 10;      // cap on the grid levels (cell edge x2 per level); the block scans take
-                                    // over as soon as fewer than n / 64 queries are pending
+#ifndef AMVS_KNN_DEBUG
+#define AMVS_KNN_DEBUG false
+#endif
 
 struct Grid {
     double lo[3];
@@ -108,15 +110,15 @@ __device__ __forceinline__ double numpy_pairwise_sum(const double (&a)[KNN_KMAX]
     return res;
 }
 
-// One pass over one grid level: queries still `pending` walk at most `max_shells` shells; those
-// that cover their k-th distance write their mean and clear the flag, the others stay pending for
-// the next (coarser) level -- or, on the last level (`allow_scan`), scan every point.
+// The cell walk: every query walks at most `max_shells` Chebyshev shells of cells around its own;
+// those that cover their k-th distance write their mean and clear the flag, the others stay pending
+// for knn_box_kernel.
 template <int K>
 __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict__ sorted, long long n, Grid gr,
                                                         const int *__restrict__ start,   // [cells + 1]
                                                         const int *__restrict__ origin,
                                                         unsigned char *__restrict__ pending,   // by original index
-                                                        int max_shells, int allow_scan,
+                                                        int max_shells,
                                                         double *__restrict__ mean_out)
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,31 +179,7 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
         if (worst <= reach * reach) { done = true; break; }
     }
     if (!done && rmax >= gmax) done = true;        // every cell was visited
-    if (!done && !allow_scan) return;              // stays pending for the next level
-    if (!done) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
-        worst = __builtin_inf();
-        const int cells = gr.g[0] * gr.g[1] * gr.g[2];
-        const int total = start[cells];
-        for (int p = 0; p < total; ++p) {
-            const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
-                         dz = qz - sorted[3 * (long long)p + 2];
-            const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
-            if (d2 < worst) {
-                bool hit_done = false;
-                double w = -1.0;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const bool hit = !hit_done & (best[j] == worst);
-                    best[j] = hit ? d2 : best[j];
-                    hit_done |= hit;
-                    w = best[j] > w ? best[j] : w;
-                }
-                worst = w;
-            }
-        }
-    }
+    if (!done) return;                             // stays pending: knn_box_kernel takes it
 
     // ascending order, sqrt, drop the first (the query itself), numpy-order mean of the other K-1
 #pragma unroll
@@ -218,79 +196,99 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
     pending[self] = 0;
 }
 
-// Queries the grid levels left pending (isolated points: the outliers this statistic exists to
-// find): one 256-thread block per query scans ALL points -- coalesced, each thread keeps the K
-// smallest of its share -- and the block then extracts the K smallest overall, one per round, with a
-// (value, thread) arg-min reduction.  A single thread walking sparse cells takes ~85 ns per
-// candidate; this scan finishes a 277 k-point cloud in a few microseconds per query.
+// Queries the cell walk of knn_query_kernel left pending: one 256-thread block per query scans the
+// BOX of cells within R Chebyshev shells of the query's cell on the same (fine) grid -- the cells of a
+// grid row are contiguous in the sorted point array, so a row of the box is one coalesced range; waves
+// take rows, lanes take points, each thread keeps the K smallest of its share -- then extracts the K
+// smallest overall, one per round, with a (value, thread) arg-min reduction, and tests the stopping rule of the cell walk: every point
+// outside the box is at least R h away, so the K-th smallest distance found is final once it is
+// <= R h.  If not, R doubles; a box that covers the grid is a full scan.  A single thread walking a
+// coarser grid took ~1.2 us per query and the coarser grids had to be re-binned (6-7 ms each on a
+// 277 k-point cloud); this takes one launch.
 template <int K>
-__global__ __launch_bounds__(256) void knn_scan_kernel(const double *__restrict__ pts, long long n,
-                                                       const int *__restrict__ queries,       // original indices
-                                                       unsigned char *__restrict__ pending,
-                                                       double *__restrict__ mean_out)
+__global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__ pts, const double *__restrict__ sorted,
+                                                      Grid gr, const int *__restrict__ start, int r_first,
+                                                      const int *__restrict__ queries, unsigned char *__restrict__ pending,
+                                                      double *__restrict__ mean_out)
 {
     const int self = queries[blockIdx.x];
     const double qx = pts[3 * (long long)self], qy = pts[3 * (long long)self + 1], qz = pts[3 * (long long)self + 2];
-    double best[KNN_KMAX];
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
-    double worst = __builtin_inf();
-    for (long long p = threadIdx.x; p < n; p += 256) {
-        const double dx = qx - pts[3 * p], dy = qy - pts[3 * p + 1], dz = qz - pts[3 * p + 2];
-        const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
-        if (d2 < worst) {
-            bool hit_done = false;
-            double w = -1.0;
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const bool hit = !hit_done & (best[j] == worst);
-                best[j] = hit ? d2 : best[j];
-                hit_done |= hit;
-                w = best[j] > w ? best[j] : w;
-            }
-            worst = w;
-        }
-    }
-    // own list ascending
-#pragma unroll
-    for (int i = 1; i < K; ++i)
-#pragma unroll
-        for (int j = K - 1; j >= i; --j) {
-            const double a = best[j - 1], b = best[j];
-            best[j - 1] = a < b ? a : b;
-            best[j] = a < b ? b : a;
-        }
+    const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ double red_v[4];
     __shared__ int red_t[4];
     __shared__ double out[KNN_KMAX];
-    int head = 0;
-    for (int t = 0; t < K; ++t) {
-        // this thread's smallest unused value (static indexing: select over the list)
-        double v = __builtin_inf();
+    for (int R = r_first;; R *= 2) {
+        const int x0 = max(cx - R, 0), x1 = min(cx + R, gr.g[0] - 1);
+        const int y0 = max(cy - R, 0), y1 = min(cy + R, gr.g[1] - 1);
+        const int z0 = max(cz - R, 0), z1 = min(cz + R, gr.g[2] - 1);
+        const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == gr.g[0] - 1 && y1 == gr.g[1] - 1 && z1 == gr.g[2] - 1;
+        double best[KNN_KMAX];
 #pragma unroll
-        for (int j = 0; j < K; ++j) v = (j == head) ? best[j] : v;
-        int who = threadIdx.x;
-        // wave arg-min, ties to the lower thread
+        for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
+        double worst = __builtin_inf();
+        const int ny = y1 - y0 + 1, rows = ny * (z1 - z0 + 1);
+        for (int row = wave; row < rows; row += 4) {
+            const int z = z0 + row / ny, y = y0 + row % ny;
+            const long long base = ((long long)z * gr.g[1] + y) * gr.g[0];
+            const int b = start[base + x0], e = start[base + x1 + 1];
+            for (int p = b + lane; p < e; p += 64) {
+                const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
+                             dz = qz - sorted[3 * (long long)p + 2];
+                const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+                if (d2 < worst) {
+                    bool hit_done = false;
+                    double w = -1.0;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(v, off);
-            const int ow = __shfl_xor(who, off);
-            const bool take = (ov < v) | ((ov == v) & (ow < who));
-            v = take ? ov : v;
-            who = take ? ow : who;
+                    for (int j = 0; j < K; ++j) {
+                        const bool hit = !hit_done & (best[j] == worst);
+                        best[j] = hit ? d2 : best[j];
+                        hit_done |= hit;
+                        w = best[j] > w ? best[j] : w;
+                    }
+                    worst = w;
+                }
+            }
         }
-        if ((threadIdx.x & 63) == 0) { red_v[threadIdx.x >> 6] = v; red_t[threadIdx.x >> 6] = who; }
-        __syncthreads();
-        double bv = red_v[0];
-        int bt = red_t[0];
+        // own list ascending, then the K smallest of the block, one per round
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const bool take = (red_v[w] < bv) | ((red_v[w] == bv) & (red_t[w] < bt));
-            bv = take ? red_v[w] : bv;
-            bt = take ? red_t[w] : bt;
+        for (int i = 1; i < K; ++i)
+#pragma unroll
+            for (int j = K - 1; j >= i; --j) {
+                const double a = best[j - 1], b2 = best[j];
+                best[j - 1] = a < b2 ? a : b2;
+                best[j] = a < b2 ? b2 : a;
+            }
+        int head = 0;
+        for (int t = 0; t < K; ++t) {
+            double v = __builtin_inf();
+#pragma unroll
+            for (int j = 0; j < K; ++j) v = (j == head) ? best[j] : v;
+            int who = threadIdx.x;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(v, off);
+                const int ow = __shfl_xor(who, off);
+                const bool take = (ov < v) | ((ov == v) & (ow < who));
+                v = take ? ov : v;
+                who = take ? ow : who;
+            }
+            if (lane == 0) { red_v[wave] = v; red_t[wave] = who; }
+            __syncthreads();
+            double bv = red_v[0];
+            int bt = red_t[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const bool take = (red_v[w] < bv) | ((red_v[w] == bv) & (red_t[w] < bt));
+                bv = take ? red_v[w] : bv;
+                bt = take ? red_t[w] : bt;
+            }
+            if ((int)threadIdx.x == bt) head += 1;
+            if (threadIdx.x == 0) out[t] = bv;
+            __syncthreads();
         }
-        if ((int)threadIdx.x == bt) head += 1;
-        if (threadIdx.x == 0) out[t] = bv;
+        const double reach = (double)R * gr.h * (1.0 - 1e-9);
+        if (whole || out[K - 1] <= reach * reach) break;         // block-uniform: `out` is shared
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -303,10 +301,11 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const double *__restrict_
 }
 
 template <int K>
-hipError_t launch_scan(const double *pts, long long n, const int *queries, int n_queries, unsigned char *pending,
-                       double *mean_out, hipStream_t st)
+hipError_t launch_box(const double *pts, const double *sorted, const Grid &gr, const int *start, int r_first,
+                      const int *queries, int n_queries, unsigned char *pending, double *mean_out, hipStream_t st)
 {
-    hipLaunchKernelGGL((knn_scan_kernel<K>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, n, queries, pending, mean_out);
+    hipLaunchKernelGGL((knn_box_kernel<K>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, sorted, gr, start, r_first,
+                       queries, pending, mean_out);
     return hipGetLastError();
 }
 
@@ -330,10 +329,10 @@ __global__ __launch_bounds__(256) void knn_iota_kernel(int *__restrict__ v, long
 
 template <int K>
 hipError_t launch_query(const double *sorted, long long n, const Grid &gr, const int *start, const int *origin,
-                        unsigned char *pending, int max_shells, int allow_scan, double *mean_out, hipStream_t st)
+                        unsigned char *pending, int max_shells, double *mean_out, hipStream_t st)
 {
     hipLaunchKernelGGL((knn_query_kernel<K>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, sorted, n, gr,
-                       start, origin, pending, max_shells, allow_scan, mean_out);
+                       start, origin, pending, max_shells, mean_out);
     return hipGetLastError();
 }
 
@@ -458,17 +457,17 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         }
         return hipSuccess;
     };
-    auto query = [&](int max_shells, int allow_scan) -> hipError_t {
+    auto query = [&](int max_shells) -> hipError_t {
         KCHK(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));     // reused as the placement cursor
         hipLaunchKernelGGL(knn_place_kernel, dim3(bx), dim3(256), 0, st, d_pts, n, d_cell, d_start, d_count,
                            d_sorted, d_origin);
         KCHK(hipGetLastError());
         switch (k) {
-        case 8: return launch_query<8>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
-        case 10: return launch_query<10>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
-        case 16: return launch_query<16>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
-        case 20: return launch_query<20>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
-        case 32: return launch_query<32>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, allow_scan, d_mean, st);
+        case 8: return launch_query<8>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
+        case 10: return launch_query<10>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
+        case 16: return launch_query<16>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
+        case 20: return launch_query<20>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
+        case 32: return launch_query<32>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
         default: return hipErrorInvalidValue;
         }
     };
@@ -484,7 +483,7 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     }
     // coarser levels (edge x2 each) pick up the queries whose neighbourhood is sparser than two
     // shells of the level before; the last level may scan
-    constexpr bool debug = false;            // per-level timings (development aid)
+    constexpr bool debug = AMVS_KNN_DEBUG;   // stage timings (development aid)
     int *d_iota = nullptr, *d_queries = nullptr, *d_nsel = nullptr;
     auto cleanup2 = [&]() {
         for (void *p : {(void *)d_iota, (void *)d_queries, (void *)d_nsel})
@@ -515,49 +514,35 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         KCHK(hipMemcpyAsync(&count, d_nsel, sizeof(int), hipMemcpyDeviceToHost, st));
         return hipStreamSynchronize(st);
     };
+    // the cell walk on the fine grid, then one cooperative box scan per query it left pending
     int left = (int)n;
-    for (int level = 0; level < KNN_LEVELS && left > 0; ++level) {
-        hipEvent_t e0, e1;
-        if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-        const bool whole_grid = cells == 1;        // a one-cell grid is a scan already
-        KCHK_D(query(KNN_SHELLS, 0));
+    {
+        hipEvent_t e0, e1, e2;
+        if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2); (void)hipEventRecord(e0, st); }
+        KCHK_D(query(KNN_SHELLS));
         KCHK_D(pending_list(left));
-        if (debug) {
-            (void)hipEventRecord(e1, st);
-            (void)hipStreamSynchronize(st);
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            std::fprintf(stderr, "knn level %d: h %.4g grid %dx%dx%d  %.2f ms, %d of %lld still pending\n", level, gr.h,
-                         gr.g[0], gr.g[1], gr.g[2], ms, left, n);
+        if (debug) (void)hipEventRecord(e1, st);
+        if (left > 0) {
+            hipError_t e = hipErrorInvalidValue;
+            const int r_first = 2 * KNN_SHELLS;
+            switch (k) {
+            case 8: e = launch_box<8>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            case 10: e = launch_box<10>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            case 16: e = launch_box<16>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            case 20: e = launch_box<20>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            case 32: e = launch_box<32>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            default: break;
+            }
+            KCHK_D(e);
         }
-        if (whole_grid || left == 0 || level == KNN_LEVELS - 1) break;
-        // the next level only pays when many queries are left; a few thousand go straight to the
-        // scans (one block per query, O(n) each) -- and ONLY a few thousand: a strongly non-uniform
-        // cloud keeps coarsening instead of scanning for a large share of its points
-        if ((long long)left * 64 < n) break;
-        h *= 2.0;
-        double unused = -1.0;
-        KCHK_D(bin(h, unused));
-    }
-    if (left > 0) {
-        hipEvent_t e0, e1;
-        if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-        hipError_t e = hipErrorInvalidValue;
-        switch (k) {
-        case 8: e = launch_scan<8>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
-        case 10: e = launch_scan<10>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
-        case 16: e = launch_scan<16>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
-        case 20: e = launch_scan<20>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
-        case 32: e = launch_scan<32>(d_pts, n, d_queries, left, d_pending, d_mean, st); break;
-        default: break;
-        }
-        KCHK_D(e);
         if (debug) {
-            (void)hipEventRecord(e1, st);
+            (void)hipEventRecord(e2, st);
             (void)hipStreamSynchronize(st);
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            std::fprintf(stderr, "knn block scans: %d queries  %.2f ms\n", left, ms);
+            float ms0 = 0.f, ms1 = 0.f;
+            (void)hipEventElapsedTime(&ms0, e0, e1);
+            (void)hipEventElapsedTime(&ms1, e1, e2);
+            std::fprintf(stderr, "knn: h %.4g grid %dx%dx%d  cell walk %.2f ms, %d of %lld pending -> box scans %.2f ms\n", gr.h,
+                         gr.g[0], gr.g[1], gr.g[2], ms0, left, n, ms1);
         }
     }
     cleanup2();

@@ -31,7 +31,7 @@ def timed(cls, name):
 
 for name in ("_prepare_images", "_prepare_images_device", "_sweep_and_backproject", "_filter_and_downsample_device"):
     timed(ds.DenseStereoReconstructor, name)
-for rep in range(2):
+for rep in range(4):
     marks.clear()
     m = ds.DenseStereoReconstructor(sc.camera, scale=1.0)
     t0 = time.time()
