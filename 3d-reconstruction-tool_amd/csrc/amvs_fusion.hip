@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void stereo_flag_kernel(const float *__restric
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x)
-        flag[i] = (conf[i] >= min_conf) & (depth[i] > 0.0f) ? 1 : 0;
+        flag[i] = ((conf[i] >= min_conf) & (depth[i] > 0.0f)) ? 1 : 0;
 }
 
 // first[j] = number of selected (ascending) indices below j*HW, j = 0 .. n_maps  (lower bounds)
