@@ -55,6 +55,7 @@ class DenseStereoReconstructor:
         self._engine = None
         self._engine_key = None
         self._engine_images = None
+        self._resident_colors = False    # the engine holds the prepared colour images (device image prep)
         self._slot = {}
 
     def reconstruct(self, images: List[dict], poses: Dict[int, CameraPose],
@@ -128,9 +129,12 @@ class DenseStereoReconstructor:
             eng.plane_sweep_batch([self._slot[jobs[j][0]] for j in js],
                                   [[self._slot[i] for i in jobs[j][1]] for j in js],
                                   depths, self.patch_size, self.consistency_thresh)
-            cols = np.stack([processed[jobs[j][0]]["color"] for j in js])
-            counts, total = eng.stereo_backproject(cols, K_inv, [(poses[jobs[j][0]].R, poses[jobs[j][0]].t) for j in js],
-                                                   min_conf)
+            view_poses = [(poses[jobs[j][0]].R, poses[jobs[j][0]].t) for j in js]
+            if self._resident_colors and processed is self._engine_images:
+                counts, total = eng.stereo_backproject_views([self._slot[jobs[j][0]] for j in js], K_inv, view_poses, min_conf)
+            else:
+                cols = np.stack([processed[jobs[j][0]]["color"] for j in js])
+                counts, total = eng.stereo_backproject(cols, K_inv, view_poses, min_conf)
             return counts, total, True
         # several batches and / or several ranks: the maps of every view are collected first
         dmaps = np.zeros((len(mine), H, W), np.float32)
@@ -198,9 +202,11 @@ class DenseStereoReconstructor:
         self._slot = {idx: s for s, idx in enumerate(indices)}
         prepared = {}
         for idx in indices:
-            color = eng.set_view_bgr8(self._slot[idx], images[idx]["image"], poses[idx].R, poses[idx].t)
-            prepared[idx] = {"color": color, "gray": None, "shape": (H, W)}
-        self._engine, self._engine_images = eng, prepared
+            img = images[idx]["image"]
+            same = (H, W) == tuple(img.shape[:2])
+            color = eng.set_view_bgr8(self._slot[idx], img, poses[idx].R, poses[idx].t, want_color=not same)
+            prepared[idx] = {"color": img if same else color, "gray": None, "shape": (H, W)}
+        self._engine, self._engine_images, self._resident_colors = eng, prepared, True
         self._engine_key = self._make_engine_key(prepared, poses)
         return prepared
 
@@ -235,6 +241,7 @@ class DenseStereoReconstructor:
         for idx in indices:
             eng.set_view(self._slot[idx], processed[idx]["gray"], poses[idx].R, poses[idx].t)
         self._engine, self._engine_key, self._engine_images = eng, key, processed
+        self._resident_colors = False
         return eng
 
     def _compute_depth_map_gpu(self, ref_idx: int, neighbor_indices: List[int], processed: Dict,

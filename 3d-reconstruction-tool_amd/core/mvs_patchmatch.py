@@ -107,6 +107,7 @@ class PatchMatchMVS:
         self._engine = None
         self._engine_key = None
         self._engine_images = None       # strong reference to the prepared dict the engine holds
+        self._resident_colors = False    # the engine holds the prepared colour images (device image prep)
         self._slot = {}
         self.last_timing = None
 
@@ -225,9 +226,12 @@ class PatchMatchMVS:
             img = images[idx]["image"]
             if img.shape[:2] != (h, w):
                 raise ValueError("all views must share one size")
-            color = eng.set_view_bgr8(self._slot[idx], img, poses[idx].R, poses[idx].t)
-            prepared[idx] = {"color": color, "gray": None, "shape": (H, W)}
-        self._engine, self._engine_images = eng, prepared
+            # the prepared colour image stays on the device for the fusion; the host copy the reference's
+            # dict holds is the input itself at scale 1 and a (small) download otherwise
+            same = (H, W) == (h, w)
+            color = eng.set_view_bgr8(self._slot[idx], img, poses[idx].R, poses[idx].t, want_color=not same)
+            prepared[idx] = {"color": img if same else color, "gray": None, "shape": (H, W)}
+        self._engine, self._engine_images, self._resident_colors = eng, prepared, True
         self._engine_key = self._make_engine_key(prepared, poses, indices)
         return prepared
 
@@ -280,6 +284,7 @@ class PatchMatchMVS:
         for idx in indices:
             eng.set_view(self._slot[idx], images[idx]["gray"], poses[idx].R, poses[idx].t)
         self._engine, self._engine_key, self._engine_images = eng, key, images
+        self._resident_colors = False            # gray uploads: the colour images stay on the host
         return eng
 
     def _run_batch(self, eng, batch):
@@ -464,9 +469,14 @@ class PatchMatchMVS:
         n = len(maps.ref_ids)
         if n == 0:
             return np.array([]).reshape(0, 3), np.array([]).reshape(0, 3), 0
-        cols = np.stack([images[i]["color"] for i in maps.ref_ids])
         K_inv = np.linalg.inv(self.K_scaled)
         torch.cuda.synchronize(maps.depth.device)
+        if getattr(self, "_resident_colors", False) and images is self._engine_images:
+            return self._engine.fuse_filter_views([self._slot[i] for i in maps.ref_ids], maps.depth.data_ptr(),
+                                                  maps.confidence.data_ptr(), K_inv,
+                                                  [(poses[i].R, poses[i].t) for i in maps.ref_ids], self.min_views,
+                                                  do_filter=True)
+        cols = np.stack([images[i]["color"] for i in maps.ref_ids])
         return self._engine.fuse_filter(None, None, cols, K_inv, [(poses[i].R, poses[i].t) for i in maps.ref_ids],
                                         self.min_views, do_filter=True,
                                         device_ptrs=(maps.depth.data_ptr(), maps.confidence.data_ptr(), n))

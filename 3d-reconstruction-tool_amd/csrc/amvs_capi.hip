@@ -45,6 +45,8 @@ struct amvs_ctx {
     // exactly code/255 (n_inexact == 0); otherwise the sweep samples the float32 maps
     uint16_t *d_pairs = nullptr;
     long long pstride = 0;              // ushorts between packed maps
+    unsigned char *d_bgr = nullptr;      // [n_views][H*W*3] prepared colour images (amvs_set_view_bgr8), lazily allocated
+    std::vector<char> have_bgr;
     int *d_flag = nullptr;               // [n_views] 1 = the view did not quantise to 8 bits losslessly
     mutable std::vector<char> exact8;    // host copy of !d_flag, refreshed lazily (flags_dirty)
     mutable bool flags_dirty = false;
@@ -666,6 +668,7 @@ int amvs_create(int device_id, int H, int W, int n_views, const float K[9], cons
     std::memcpy(c->Kinv, K_inv, 36);
     c->R.resize(n_views); c->t.resize(n_views); c->have.assign(n_views, 0);
     c->exact8.assign(n_views, 0);
+    c->have_bgr.assign(n_views, 0);
     c->pstride = ((amvs::pair_map_elems(H, W) + 63) / 64) * 64 + 64;
     auto bail = [&](const char *what, hipError_t e) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
@@ -725,6 +728,7 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_bgr) (void)hipFree(c->d_bgr);
     for (auto &kv : c->stats) {
         if (kv.second.mean) (void)hipFree(kv.second.mean);
         if (kv.second.var) (void)hipFree(kv.second.var);
@@ -769,6 +773,7 @@ static int set_view_common(amvs_ctx *c, int view, const void *gray, const float 
     HIPCHK(c, amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W,
                                       c->d_pairs + view * c->pstride, c->d_flag + view, c->stream));
     c->flags_dirty = true;
+    c->have_bgr[view] = 0;
     // a host buffer is the caller's again on return; a device buffer is only ordered on the stream
     if (kind == hipMemcpyHostToDevice) HIPCHK(c, hipStreamSynchronize(c->stream));
     std::memcpy(c->R[view].data(), R, 36);
@@ -813,16 +818,16 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
     std::vector<short> ialpha, ibeta;
     resize_axis_tables(c->W, src_w, xofs, ialpha, true);
     resize_axis_tables(c->H, src_h, yofs, ibeta, false);
-    unsigned char *d_src = nullptr, *d_scaled = nullptr;
+    // the prepared colour image stays on the device (the fusion reads it there: amvs_fuse_filter_views)
+    if (!c->d_bgr) HIPCHK(c, hipMalloc(&c->d_bgr, 3 * n_dst * (size_t)c->n_views));
+    unsigned char *d_src = nullptr, *d_scaled = c->d_bgr + 3 * n_dst * (size_t)view;
     int *d_tab = nullptr;
     const size_t tab_ints = (size_t)c->W + c->H, tab_shorts = 2 * ((size_t)c->W + c->H);
     auto cleanup = [&]() {
         if (d_src) (void)hipFree(d_src);
-        if (d_scaled) (void)hipFree(d_scaled);
         if (d_tab) (void)hipFree(d_tab);
     };
     hipError_t e = hipMalloc(&d_src, 3 * n_src);
-    if (e == hipSuccess) e = hipMalloc(&d_scaled, 3 * n_dst);
     if (e == hipSuccess) e = hipMalloc(&d_tab, 4 * tab_ints + 2 * tab_shorts);
     int *d_xofs = d_tab, *d_yofs = d_tab ? d_tab + c->W : nullptr;
     short *d_ialpha = d_tab ? (short *)(d_tab + tab_ints) : nullptr, *d_ibeta = d_ialpha ? d_ialpha + 2 * c->W : nullptr;
@@ -844,6 +849,7 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
     cleanup();
     if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("set_view_bgr8: ") + hipGetErrorString(e));
     c->flags_dirty = true;
+    c->have_bgr[view] = 1;
     std::memcpy(c->R[view].data(), R, 36);
     std::memcpy(c->t[view].data(), t, 12);
     c->have[view] = 1;
@@ -1161,6 +1167,40 @@ int amvs_stereo_backproject(amvs_ctx *c, int n_maps, const void *depth, const vo
     return AMVS_OK;
 }
 
+int amvs_stereo_backproject_views(amvs_ctx *c, int n_maps, const int *view_ids, const double K_inv[9], const double *poses,
+                                  float min_confidence, int64_t *per_map_counts, int64_t *total)
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_maps < 1 || !view_ids || !K_inv || !poses || !total) return fail(c, AMVS_EINVAL, "bad argument");
+    if (n_maps != c->n_sweep) return fail(c, AMVS_EINVAL, "n_maps differs from the resident plane-sweep batch");
+    for (int j = 0; j < n_maps; ++j)
+        if (view_ids[j] < 0 || view_ids[j] >= c->n_views || !c->have_bgr[view_ids[j]])
+            return fail(c, AMVS_EINVAL, "view " + std::to_string(view_ids[j]) + " has no resident colour image (amvs_set_view_bgr8)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    c->d_cloud_pts = nullptr; c->d_cloud_rgb = nullptr; c->cloud_n = 0;
+    unsigned char *dbgr = nullptr;
+    hipError_t e = hipMalloc(&dbgr, 3 * hw * (size_t)n_maps);
+    for (int j = 0; j < n_maps && e == hipSuccess; ++j)
+        e = hipMemcpyAsync(dbgr + 3 * hw * (size_t)j, c->d_bgr + 3 * hw * (size_t)view_ids[j], 3 * hw,
+                           hipMemcpyDeviceToDevice, c->stream);
+    long long tot = 0;
+    std::vector<long long> per(n_maps, 0);
+    if (e == hipSuccess)
+        e = amvs::stereo_backproject(c->d_sweep_depth, c->d_sweep_conf, dbgr, n_maps, c->H, c->W, K_inv, poses, min_confidence,
+                                     &c->d_cloud_pts, &c->d_cloud_rgb, &tot, per.data(), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    if (dbgr) (void)hipFree(dbgr);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("stereo_backproject_views: ") + hipGetErrorString(e));
+    c->cloud_n = tot;
+    *total = tot;
+    if (per_map_counts) for (int j = 0; j < n_maps; ++j) per_map_counts[j] = per[j];
+    return AMVS_OK;
+}
+
 int amvs_cloud_knn_mean_distance(amvs_ctx *c, int k, double *mean_out)
 {
     if (!c) return AMVS_EINVAL;
@@ -1450,6 +1490,41 @@ int amvs_fuse_filter(amvs_ctx *c, int n_maps, const void *depth, const void *con
     (void)hipStreamSynchronize(c->stream);
     cleanup();
     if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("fuse_filter: ") + hipGetErrorString(e));
+    counts[0] = cnt[0]; counts[1] = cnt[1];
+    c->cloud_n = cnt[1];
+    return AMVS_OK;
+}
+
+int amvs_fuse_filter_views(amvs_ctx *c, int n_maps, const int *view_ids, const void *depth_dev, const void *conf_dev,
+                           const double K_inv[9], const double *poses, float min_views, int do_filter,
+                           int64_t counts[2])
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_maps < 1 || !view_ids || !depth_dev || !conf_dev || !K_inv || !poses || !counts)
+        return fail(c, AMVS_EINVAL, "bad argument");
+    for (int j = 0; j < n_maps; ++j)
+        if (view_ids[j] < 0 || view_ids[j] >= c->n_views || !c->have_bgr[view_ids[j]])
+            return fail(c, AMVS_EINVAL, "view " + std::to_string(view_ids[j]) + " has no resident colour image (amvs_set_view_bgr8)");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    c->d_cloud_pts = nullptr; c->d_cloud_rgb = nullptr; c->cloud_n = 0;
+    // the maps' colour images in map order (device-to-device; the images of a scene are rarely in
+    // that order already)
+    unsigned char *dbgr = nullptr;
+    hipError_t e = hipMalloc(&dbgr, 3 * hw * (size_t)n_maps);
+    for (int j = 0; j < n_maps && e == hipSuccess; ++j)
+        e = hipMemcpyAsync(dbgr + 3 * hw * (size_t)j, c->d_bgr + 3 * hw * (size_t)view_ids[j], 3 * hw,
+                           hipMemcpyDeviceToDevice, c->stream);
+    long long cnt[2] = {0, 0};
+    if (e == hipSuccess)
+        e = amvs::fuse_filter((const float *)depth_dev, (const float *)conf_dev, dbgr, n_maps, c->H, c->W, K_inv, poses,
+                              min_views, do_filter != 0, &c->d_cloud_pts, &c->d_cloud_rgb, cnt, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    if (dbgr) (void)hipFree(dbgr);
+    if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("fuse_filter_views: ") + hipGetErrorString(e));
     counts[0] = cnt[0]; counts[1] = cnt[1];
     c->cloud_n = cnt[1];
     return AMVS_OK;

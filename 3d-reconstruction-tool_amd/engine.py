@@ -387,6 +387,44 @@ class Engine:
                                                  rgb.ctypes.data_as(C.POINTER(C.c_uint8))))
         return pts, rgb, int(counts[0])
 
+    def stereo_backproject_views(self, view_ids, K_inv64, poses, min_confidence):
+        """stereo_backproject for the resident maps of the last plane_sweep_batch with the colour images
+        set_view_bgr8 left on the device (map j belongs to view view_ids[j]).  Returns (per-view point
+        counts, total); the cloud stays on the device."""
+        ids, idp = _ids(view_ids)
+        n = ids.shape[0]
+        kinv = np.ascontiguousarray(K_inv64, dtype=np.float64).reshape(9)
+        pp = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(R, np.float64).reshape(9),
+                                                            np.asarray(t, np.float64).reshape(3)])
+                                            for R, t in poses]))
+        per = (C.c_int64 * n)()
+        total = C.c_int64(0)
+        self._chk(self._lib.amvs_stereo_backproject_views(
+            self._h, n, idp, kinv.ctypes.data_as(C.POINTER(C.c_double)), pp.ctypes.data_as(C.POINTER(C.c_double)),
+            float(min_confidence), per, C.byref(total)))
+        return [int(x) for x in per], int(total.value)
+
+    def fuse_filter_views(self, view_ids, depth_ptr, conf_ptr, K_inv64, poses, min_views, do_filter=True):
+        """Device fusion (+ filter) of resident maps whose colour images are resident as well
+        (set_view_bgr8): map j belongs to view view_ids[j].  Returns (points, colors RGB, raw_count)."""
+        ids, idp = _ids(view_ids)
+        n = ids.shape[0]
+        kinv = np.ascontiguousarray(K_inv64, dtype=np.float64).reshape(9)
+        pp = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(R, np.float64).reshape(9),
+                                                            np.asarray(t, np.float64).reshape(3)])
+                                            for R, t in poses]))
+        counts = (C.c_int64 * 2)()
+        self._chk(self._lib.amvs_fuse_filter_views(
+            self._h, n, idp, C.c_void_p(depth_ptr), C.c_void_p(conf_ptr), kinv.ctypes.data_as(C.POINTER(C.c_double)),
+            pp.ctypes.data_as(C.POINTER(C.c_double)), float(min_views), int(bool(do_filter)), counts))
+        m = int(counts[1])
+        pts = np.empty((m, 3), np.float64)
+        rgb = np.empty((m, 3), np.uint8)
+        if m:
+            self._chk(self._lib.amvs_fetch_cloud(self._h, pts.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 rgb.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return pts, rgb, int(counts[0])
+
     def knn_mean_distance(self, points, k=20):
         """Mean distance of every point to its k-1 nearest other points, bit-identical to
         np.mean(NearestNeighbors(n_neighbors=k).fit(p).kneighbors(p)[0][:, 1:], axis=1)."""

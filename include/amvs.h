@@ -178,6 +178,11 @@ int amvs_fetch_sweep_maps(amvs_ctx *ctx, int first, int count, float *depth_out,
 int amvs_stereo_backproject(amvs_ctx *ctx, int n_maps, const void *depth, const void *conf, int maps_where,
                             const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
                             float min_confidence, int64_t *per_map_counts, int64_t *total);
+/* The same for the resident plane-sweep batch and resident colour images (amvs_set_view_bgr8): map j
+ * belongs to view view_ids[j]; nothing is uploaded.                                              */
+int amvs_stereo_backproject_views(amvs_ctx *ctx, int n_maps, const int *view_ids, const double K_inv[9],
+                                  const double *poses, float min_confidence, int64_t *per_map_counts,
+                                  int64_t *total);
 /* amvs_knn_mean_distance on the context's resident cloud (the result of amvs_stereo_backproject /
  * amvs_fuse_filter): the statistic of _filter_outliers without a host round trip of the points.     */
 int amvs_cloud_knn_mean_distance(amvs_ctx *ctx, int k, double *mean_out);
@@ -208,6 +213,12 @@ int amvs_knn_mean_distance(amvs_ctx *ctx, const double *points, int64_t n, int k
 int amvs_fuse_filter(amvs_ctx *ctx, int n_maps, const void *depth, const void *conf, int maps_on_device,
                      const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
                      float min_views, int do_filter, int64_t counts[2]);
+/* The same fusion + filter for maps resident on the device whose colour images are resident too:
+ * map j belongs to view view_ids[j], whose prepared BGR image amvs_set_view_bgr8 left on the device
+ * (no host colour array: 3 B/pixel of upload per map saved).  Same results as amvs_fuse_filter.   */
+int amvs_fuse_filter_views(amvs_ctx *ctx, int n_maps, const int *view_ids, const void *depth_dev, const void *conf_dev,
+                           const double K_inv[9], const double *poses, float min_views, int do_filter,
+                           int64_t counts[2]);
 int amvs_fetch_cloud(amvs_ctx *ctx, double *points_out, uint8_t *colors_out);
 
 /* ---- extended mode: what the reference's docstring names but does not implement ----------------

@@ -669,3 +669,32 @@ def test_error_paths(eng_a, scene_a, amvs_mod):
         eng_a.eval_cost(2, [1, 17], 7, d)
     with pytest.raises(AmvsError):
         amvs_mod.Engine(0, 10, 3, np.eye(3))
+
+
+def test_resident_colour_entry_points_need_device_prepared_views(amvs_mod):
+    """amvs_fuse_filter_views / amvs_stereo_backproject_views read the colour images amvs_set_view_bgr8
+    leaves on the device; a view uploaded as a gray map has none, and the call says so.  With device-
+    prepared views the cloud equals the one fused from host colour arrays."""
+    import torch
+    from amvs.synthetic import make_scene
+    sc = make_scene(3, 40, 56, seed=5)
+    K = sc.camera.K.astype(np.float32)
+    K_inv = np.linalg.inv(sc.camera.K)
+    dev = torch.device("cuda", 0)
+    depth = torch.from_numpy(np.stack([sc.depths[i] for i in range(3)]).astype(np.float32)).to(dev)
+    conf = torch.full((3, 40, 56), 3.0, dtype=torch.float32, device=dev)
+    view_poses = [(sc.poses[i].R, sc.poses[i].t) for i in range(3)]
+    with amvs_mod.Engine(40, 56, 3, K) as eng:
+        for i in range(3):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        with pytest.raises(amvs_mod.AmvsError, match="no resident colour image"):
+            eng.fuse_filter_views([0, 1, 2], depth.data_ptr(), conf.data_ptr(), K_inv, view_poses, 3)
+        bgr = [np.ascontiguousarray(sc.colors[i][:, :, ::-1]) for i in range(3)]
+        for i in range(3):
+            eng.set_view_bgr8(i, bgr[i], sc.poses[i].R, sc.poses[i].t, want_color=False)
+        torch.cuda.synchronize()
+        p1, c1, raw1 = eng.fuse_filter_views([2, 0, 1], depth[[2, 0, 1]].contiguous().data_ptr(),
+                                             conf.data_ptr(), K_inv, [view_poses[j] for j in (2, 0, 1)], 3)
+        p2, c2, raw2 = eng.fuse_filter(depth[[2, 0, 1]].cpu().numpy(), conf.cpu().numpy(), np.stack([bgr[j] for j in (2, 0, 1)]),
+                                       K_inv, [view_poses[j] for j in (2, 0, 1)], 3)
+    assert raw1 == raw2 and np.array_equal(p1, p2) and np.array_equal(c1, c2)

@@ -33,9 +33,9 @@ def timed(cls, name):
 
 
 for name in ("_prepare_images", "_sweep", "_sweep_resident", "_fuse_filter_device", "_fuse_filter_resident",
-             "_estimate_depth_range"):
+             "_estimate_depth_range", "_prepare_images_device"):
     timed(mp.PatchMatchMVS, name)
-for rep in range(2):
+for rep in range(4):
     marks.clear()
     m = mp.PatchMatchMVS(sc.camera, scale=scale, patch_size=7, num_iterations=8, num_samples=8)
     t0 = time.time()
