@@ -102,6 +102,7 @@ SIGNATURES = {
                                C.POINTER(C.c_double), C.c_float, C.c_int, C.POINTER(C.c_int64)]),
     "amvs_stereo_backproject_views": (C.c_int, [C.c_void_p, C.c_int, i32p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "amvs_set_view_colors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint8)]),
     "amvs_fetch_cloud": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
     "amvs_write_ply": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64]),
     "amvs_knn_mean_distance": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double)]),

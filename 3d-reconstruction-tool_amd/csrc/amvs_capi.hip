@@ -858,6 +858,20 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
     return AMVS_OK;
 }
 
+int amvs_set_view_colors(amvs_ctx *c, int view, const uint8_t *bgr_host)
+{
+    if (!c) return AMVS_EINVAL;
+    if (view < 0 || view >= c->n_views || !bgr_host) return fail(c, AMVS_EINVAL, "bad view argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->H * c->W;
+    if (!c->d_bgr) HIPCHK(c, hipMalloc(&c->d_bgr, 3 * n * (size_t)c->n_views));
+    HIPCHK(c, hipMemcpyAsync(c->d_bgr + 3 * n * (size_t)view, bgr_host, 3 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_bgr[view] = 1;
+    return AMVS_OK;
+}
+
 int amvs_set_view(amvs_ctx *c, int view, const float *gray_host, const float R[9], const float t[3])
 {
     return set_view_common(c, view, gray_host, R, t, hipMemcpyHostToDevice);

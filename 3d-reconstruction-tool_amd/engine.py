@@ -133,6 +133,14 @@ class Engine:
             out.ctypes.data_as(C.POINTER(C.c_uint8)) if want_color else None))
         return out
 
+    def set_view_colors(self, view, image_bgr_u8):
+        """Keep the (H, W, 3) uint8 BGR image of a view on the device for fuse_filter_views /
+        stereo_backproject_views (views prepared with set_view_bgr8 have theirs already)."""
+        img = np.ascontiguousarray(image_bgr_u8, dtype=np.uint8)
+        if img.shape != (self.H, self.W, 3):
+            raise ValueError(f"expected a ({self.H}, {self.W}, 3) uint8 BGR image")
+        self._chk(self._lib.amvs_set_view_colors(self._h, int(view), img.ctypes.data_as(C.POINTER(C.c_uint8))))
+
     def set_view_device(self, view, gray_ptr, R, t):
         R = _f32(np.asarray(R, np.float64).astype(np.float32).reshape(3, 3))
         t = _f32(np.asarray(t, np.float64).astype(np.float32).reshape(3))

@@ -198,6 +198,7 @@ def main():
         sc.grays[i] = g.cpu().numpy()
         eng.set_view_device(i, g.data_ptr(), sc.poses[i].R, sc.poses[i].t)
         torch.cuda.synchronize()
+        eng.set_view_colors(i, np.ascontiguousarray(sc.colors[i]))     # for the device fusion (amvs_fuse_filter_views)
     params = make_pm_params(args.patch, args.iters, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
                             args.views_per_launch, schedule=args.schedule)
     eng.set_split_tuning(args.split_groups, args.split_rows, args.split_lds)
@@ -230,8 +231,8 @@ def main():
     if args.fusion:
         # config 5: the fused, filtered cloud is part of the step (on rank 0, which like every rank
         # holds all maps after the gather)
-        fusion_inputs = (np.stack([sc.colors[r] for r in ids]), np.linalg.inv(sc.camera.K),
-                         [(sc.poses[r].R, sc.poses[r].t) for r in ids])
+        fusion_inputs = (None if backend != "gloo" or world == 1 else np.stack([sc.colors[r] for r in ids]),
+                         np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in ids])
     in_flight = []
     state = {"step": 0, "cloud": None, "fusion_s": 0.0}
 
@@ -245,12 +246,10 @@ def main():
         cols, K_inv, pose_list = fusion_inputs
         if world == 1:
             torch.cuda.synchronize()
-            out = eng.fuse_filter(None, None, cols, K_inv, pose_list, 3, True,
-                                  device_ptrs=(depth[k].data_ptr(), conf[k].data_ptr(), n_loc))
+            out = eng.fuse_filter_views(ids, depth[k].data_ptr(), conf[k].data_ptr(), K_inv, pose_list, 3, True)
         elif backend == "nccl":
             torch.cuda.synchronize()
-            out = eng.fuse_filter(None, None, cols, K_inv, pose_list, 3, True,
-                                  device_ptrs=(full[k]["d"].data_ptr(), full[k]["c"].data_ptr(), n_views))
+            out = eng.fuse_filter_views(ids, full[k]["d"].data_ptr(), full[k]["c"].data_ptr(), K_inv, pose_list, 3, True)
         else:
             out = eng.fuse_filter(full[k]["d"].numpy().reshape(n_views, H, W), full[k]["c"].numpy().reshape(n_views, H, W),
                                   cols, K_inv, pose_list, 3, True)
@@ -380,9 +379,9 @@ def main():
         elif world == 1:
             torch.cuda.synchronize()
             t_f = time.perf_counter()
-            pts, cols, raw = eng.fuse_filter(None, None, np.stack([sc.colors[r] for r in refs]),
-                                             np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in refs],
-                                             3, True, device_ptrs=(depth[k_last].data_ptr(), conf[k_last].data_ptr(), n_loc))
+            pts, cols, raw = eng.fuse_filter_views(refs, depth[k_last].data_ptr(), conf[k_last].data_ptr(),
+                                                   np.linalg.inv(sc.camera.K),
+                                                   [(sc.poses[r].R, sc.poses[r].t) for r in refs], 3, True)
             t_f = time.perf_counter() - t_f
             out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": False,
                                    "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),

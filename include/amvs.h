@@ -213,6 +213,11 @@ int amvs_knn_mean_distance(amvs_ctx *ctx, const double *points, int64_t n, int k
 int amvs_fuse_filter(amvs_ctx *ctx, int n_maps, const void *depth, const void *conf, int maps_on_device,
                      const uint8_t *colors_bgr_host, const double K_inv[9], const double *poses,
                      float min_views, int do_filter, int64_t counts[2]);
+/* Colour image (H x W x 3 uint8 BGR, at the context's size, host) of a view whose gray map was
+ * uploaded with amvs_set_view[_device]: kept on the device for the *_views entry points below.
+ * (amvs_set_view_bgr8 leaves the image it prepared there by itself; a later amvs_set_view[_device] of
+ * the same view drops it.)                                                                        */
+int amvs_set_view_colors(amvs_ctx *ctx, int view, const uint8_t *bgr_host);
 /* The same fusion + filter for maps resident on the device whose colour images are resident too:
  * map j belongs to view view_ids[j], whose prepared BGR image amvs_set_view_bgr8 left on the device
  * (no host colour array: 3 B/pixel of upload per map saved).  Same results as amvs_fuse_filter.   */
