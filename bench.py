@@ -274,8 +274,14 @@ def main():
                         if backend != "nccl":
                             comm_stream.synchronize()
                             inp = inp.cpu()
-                        outs = [full[k][name][r, lo:hi] for r in range(world)]
-                        works.append(dist.all_gather(outs, inp, async_op=True))
+                        if nb == 1:
+                            # the rank's whole block at once: straight into the (world, n_loc, width) array,
+                            # no list of output views for the backend to assemble
+                            works.append(dist.all_gather_into_tensor(full[k][name].view(world * n_loc, -1), inp,
+                                                                     async_op=True))
+                        else:
+                            outs = [full[k][name][r, lo:hi] for r in range(world)]
+                            works.append(dist.all_gather(outs, inp, async_op=True))
         eng.sync()
         if world > 1:
             in_flight.append(works)
