@@ -63,6 +63,9 @@ SIGNATURES = {
     "amvs_get_mode": (C.c_int, [C.c_void_p]),
     "amvs_set_sweep_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "amvs_set_split_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "amvs_set_step_tuning": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p]),
+    "amvs_set_step_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "amvs_get_step_times": (C.c_int, [C.c_void_p, f32p, C.c_int, i32p]),
     "amvs_last_tile_rows": (C.c_int, [C.c_void_p]),
     "amvs_last_views_per_launch": (C.c_int, [C.c_void_p]),
     "amvs_plane_sweep": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, f32p, C.c_int, C.c_int,

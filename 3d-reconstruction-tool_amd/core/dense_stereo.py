@@ -27,13 +27,22 @@ from .. import engine as _engine
 from .. import parallel as _parallel
 
 
+def _torch_cuda():
+    """torch with a usable HIP device, or None (then maps travel through host arrays)."""
+    try:
+        import torch
+    except Exception:  # noqa: BLE001
+        return None
+    return torch if torch.cuda.is_available() else None
+
+
 class DenseStereoReconstructor:
     NUM_NEIGHBORS = 6        # reference :109
 
     def __init__(self, camera: Camera, scale: float = 0.25, num_depths: int = 64,
                  patch_size: int = 5, min_views: int = 3, consistency_thresh: float = 0.8, *,
-                 device: Optional[int] = None, device_filter: bool = True, mode: str = "fast",
-                 process_group=None, device_prep: bool = True):
+                 device: Optional[int] = None, device_filter: bool = True, mode: str = "exact",
+                 process_group=None, device_prep: Optional[bool] = None):
         self.camera = camera
         self.scale = scale
         self.num_depths = num_depths
@@ -43,7 +52,10 @@ class DenseStereoReconstructor:
         self.device_id = _parallel.local_device() if device is None else int(device)
         self.device_filter = device_filter       # outlier filter's neighbour search on the GPU
         self.process_group = process_group       # torch.distributed group the reference views are sharded over
-        self.device_prep = device_prep           # resize / gray conversion on the GPU (amvs_set_view_bgr8)
+        # resize / gray conversion on the GPU (amvs_set_view_bgr8): the default only where cv2 is not
+        # importable (see PatchMatchMVS.__init__)
+        from . import imageprep as _ip
+        self.device_prep = (_ip._cv is None) if device_prep is None else bool(device_prep)
         if mode not in ("exact", "fast"):
             raise ValueError("mode must be 'exact' or 'fast'")
         self.mode = mode                         # arithmetic of the sweep (include/amvs.h AMVS_MODE_*)
@@ -136,31 +148,61 @@ class DenseStereoReconstructor:
                 cols = np.stack([processed[jobs[j][0]]["color"] for j in js])
                 counts, total = eng.stereo_backproject(cols, K_inv, view_poses, min_conf)
             return counts, total, True
-        # several batches and / or several ranks: the maps of every view are collected first
+        # several batches and / or several ranks: the maps of every view are collected first -- in
+        # device tensors when torch-ROCm is there (job j in row j; the sweeps write their rows, RCCL
+        # gathers the rank blocks in place, the back-projection reads them: nothing crosses PCIe)
+        torch = _torch_cuda()
+        runs, cur = [], []
+        for j in mine:                                     # launches = runs of consecutive jobs, one neighbour count
+            if cur and (len(jobs[j][1]) != len(jobs[cur[-1]][1]) or j != cur[-1] + 1):
+                runs.append(cur)
+                cur = []
+            cur.append(j)
+        if cur:
+            runs.append(cur)
+        order = list(range(len(jobs))) if world > 1 else mine
+        view_poses = [(poses[jobs[j][0]].R, poses[jobs[j][0]].t) for j in order]
+        cols = np.stack([processed[jobs[j][0]]["color"] for j in order])
+        if torch is not None:
+            dev = torch.device("cuda", self.device_id)
+            hw = H * W
+            per = (len(jobs) + world - 1) // world
+            base = rank * per
+            dmaps = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
+            cmaps = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
+            for js in runs:
+                eng.plane_sweep_device([self._slot[jobs[j][0]] for j in js],
+                                       [[self._slot[i] for i in jobs[j][1]] for j in js],
+                                       depths, self.patch_size, self.consistency_thresh,
+                                       dmaps[js[0]].data_ptr(), cmaps[js[0]].data_ptr())
+            eng.sync()
+            if world > 1:
+                direct = torch.distributed.get_backend(self.process_group) == "nccl"
+                for t in (dmaps, cmaps):
+                    block = t[base: base + per]
+                    if direct:
+                        torch.distributed.all_gather_into_tensor(t, block.clone(), group=self.process_group)
+                    else:                                  # gloo (tests): staged through the host
+                        full = torch.empty((world * per, hw), dtype=torch.float32)
+                        torch.distributed.all_gather_into_tensor(full, block.cpu(), group=self.process_group)
+                        t.copy_(full)
+                torch.cuda.synchronize(dev)
+            first = 0 if world > 1 else mine[0]
+            counts, total = eng.stereo_backproject(cols, K_inv, view_poses, min_conf,
+                                                   device_ptrs=(dmaps[first].data_ptr(), cmaps[first].data_ptr()))
+            return counts, total, True
         dmaps = np.zeros((len(mine), H, W), np.float32)
         cmaps = np.zeros((len(mine), H, W), np.float32)
         row = {j: n for n, j in enumerate(mine)}
-        for _, js in sorted(groups.items()):
+        for js in runs:
             eng.plane_sweep_batch([self._slot[jobs[j][0]] for j in js],
                                   [[self._slot[i] for i in jobs[j][1]] for j in js],
                                   depths, self.patch_size, self.consistency_thresh)
             d, c = eng.fetch_sweep_maps(0, len(js))
             for n, j in enumerate(js):
                 dmaps[row[j]], cmaps[row[j]] = d[n], c[n]
-        if world > 1:
-            import torch
-            packed = torch.from_numpy(np.concatenate([dmaps.reshape(len(mine), -1), cmaps.reshape(len(mine), -1)], axis=1))
-            if torch.distributed.get_backend(self.process_group) == "nccl":
-                packed = packed.to(torch.device("cuda", self.device_id))
-            full = _parallel.allgather_packed(packed, len(jobs), 2 * H * W, self.process_group).cpu().numpy()
-            dmaps = full[:, : H * W].reshape(len(jobs), H, W)
-            cmaps = full[:, H * W:].reshape(len(jobs), H, W)
-            order = list(range(len(jobs)))
-        else:
-            order = mine
-        cols = np.stack([processed[jobs[j][0]]["color"] for j in order])
-        counts, total = eng.stereo_backproject(cols, K_inv, [(poses[jobs[j][0]].R, poses[jobs[j][0]].t) for j in order],
-                                               min_conf, depth=dmaps, conf=cmaps)
+        counts, total = eng.stereo_backproject(cols, K_inv, view_poses, min_conf, depth=dmaps, conf=cmaps)
         return counts, total, True
 
     def _filter_and_downsample_device(self, eng, total, voxel_size, k=20, std_ratio=2.0):

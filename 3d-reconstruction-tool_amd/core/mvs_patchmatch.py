@@ -15,9 +15,9 @@ Differences a caller can observe, all opt-in or performance-only:
   * `seed` names the RNG streams (the reference is unseeded);
   * `mode` selects the arithmetic of the sweep kernels: "exact" reproduces the reference's float32
     operation sequence (bit-identical to the tests' CPU restatement, which matches torch-CPU up to
-    the box filter's summation order), "fast" (default) is the tolerance mode of include/amvs.h
-    AMVS_MODE_FAST -- measured against the reference's golden vectors it agrees exactly as well
-    as "exact" does (see DESIGN.md section 2);
+    the box filter's summation order; the default), "fast" is the tolerance mode of include/amvs.h
+    AMVS_MODE_FAST (what bench.py times) -- measured against the reference's golden vectors it
+    agrees exactly as well as "exact" does (see DESIGN.md section 2);
   * under an initialised torch.distributed process group the reference views are
     sharded over ranks and the per-view maps are all-gathered (see ..parallel);
   * with `device_fusion` (default) and torch-ROCm present the per-view maps never leave
@@ -60,6 +60,11 @@ class _ResidentMaps:
                                   confidence=c[i].reshape(H, W)) for i, r in enumerate(self.ref_ids)}
 
 
+def _imageprep_has_cv2():
+    from . import imageprep
+    return imageprep._cv is not None
+
+
 def _torch_cuda():
     """torch with a usable HIP device, or None (then maps travel through host arrays)."""
     try:
@@ -76,8 +81,8 @@ class PatchMatchMVS:
                  num_iterations: int = 3, num_samples: int = 8, min_views: int = 3,
                  depth_min: float = 0.1, depth_max: float = 100.0, *,
                  seed: int = 0, device: Optional[int] = None, views_per_batch: int = 16,
-                 process_group=None, device_fusion: bool = True, mode: str = "fast",
-                 device_prep: bool = True, extended: bool = False):
+                 process_group=None, device_fusion: bool = True, mode: str = "exact",
+                 device_prep: Optional[bool] = None, extended: bool = False, gather_normals: bool = True):
         self.camera = camera
         self.scale = scale
         self.patch_size = patch_size
@@ -90,7 +95,14 @@ class PatchMatchMVS:
         self.views_per_batch = max(1, int(views_per_batch))
         self.process_group = process_group
         self.device_fusion = device_fusion
-        self.device_prep = device_prep           # resize / gray conversion on the GPU (amvs_set_view_bgr8)
+        # resize / gray conversion on the GPU (amvs_set_view_bgr8).  The device arithmetic restates
+        # OpenCV's 8-bit algorithm and cannot be pinned against cv2 in the build container (DESIGN.md
+        # section 2), so the default is the device path only where cv2 is NOT importable; where it is,
+        # the host path calls cv2 itself and is the reference's by construction.
+        self.device_prep = (not _imageprep_has_cv2()) if device_prep is None else bool(device_prep)
+        # several ranks: also all-gather the normal maps (12 of the 20 B/pixel; north_star's exchange).
+        # reconstruct() itself fuses depth and confidence only (reference :536-570).
+        self.gather_normals = gather_normals
         # Extended mode (off by default, NO reference counterpart -- the reference's docstring names view
         # propagation and plane normals, :1-13, its code implements neither): slanted-plane cost,
         # red-black propagation, view propagation fed by the other views' maps (all-gathered between
@@ -333,10 +345,32 @@ class PatchMatchMVS:
                                              self.process_group, DepthNormalMap, device_id=self.device_id)
         return {jobs[j][0]: local[j] for j in sorted(local)}
 
+    def _batches_in_row_order(self, jobs, mine, cap):
+        """This rank's jobs as launches: runs of consecutive jobs with one source count, at most `cap`
+        long, in row order (a launch writes its views to consecutive rows of the output tensors)."""
+        runs, cur = [], []
+        for j in mine:
+            if cur and (len(jobs[j][1]) != len(jobs[cur[-1]][1]) or j != cur[-1] + 1 or len(cur) == cap):
+                runs.append(cur)
+                cur = []
+            cur.append(j)
+        if cur:
+            runs.append(cur)
+        return runs
+
     def _sweep_resident(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
         """_sweep with the maps kept in device tensors: this rank's views are swept straight into
-        them (amvs_patchmatch_device), the all-gather runs on them (RCCL) and the valid-pixel
-        counts of the progress lines are reduced on the GPU."""
+        its block of rows (amvs_patchmatch_device) and the valid-pixel counts of the progress lines are
+        reduced on the GPU.
+
+        Several ranks: every rank's block is `per` = ceil(n / world) rows of ONE tensor in job order, cut
+        into the same row groups on every rank (at least two, so that a 4-view shard still overlaps);
+        the launches are capped at a group, and as soon as the launches covering a group are enqueued its
+        all-gather (RCCL: three collectives -- depth, confidence, normals -- on a second stream, ordered
+        after the sweep by an event) runs under the sweep of the next group.  Only the last group's
+        exchange is exposed.  No host synchronisation happens between the first launch and the last
+        collective; the progress lines are printed afterwards.  The reference loops serially and has no
+        exchange (:104-123)."""
         n_cams = len(cam_indices)
         rank, world = _parallel.rank_world(self.process_group)
         mine = _parallel.shard(len(jobs), rank, world)
@@ -344,27 +378,15 @@ class PatchMatchMVS:
         H, W = proc_images[cam_indices[0]]["shape"]
         hw = H * W
         dev = torch.device("cuda", self.device_id)
-        depth = torch.empty((len(mine), hw), dtype=torch.float32, device=dev)
-        normal = torch.empty((len(mine), 3 * hw), dtype=torch.float32, device=dev)
-        conf = torch.empty((len(mine), hw), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize(dev)
-        row = {j: n for n, j in enumerate(mine)}
-        by_count = {}
-        for j in mine:
-            by_count.setdefault(len(jobs[j][1]), []).append(j)
-        # a batch writes its views to consecutive rows, so the batches are runs of consecutive jobs
-        for _, idxs in sorted(by_count.items()):
-            runs, cur = [], []
-            for j in idxs:
-                if cur and (j != cur[-1] + 1 or len(cur) == self.views_per_batch):
-                    runs.append(cur)
-                    cur = []
-                cur.append(j)
-            if cur:
-                runs.append(cur)
-            for chunk in runs:
+        n = len(jobs)
+        if world == 1:
+            depth = torch.empty((n, hw), dtype=torch.float32, device=dev)
+            normal = torch.empty((n, 3 * hw), dtype=torch.float32, device=dev)
+            conf = torch.empty((n, hw), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize(dev)
+            for chunk in self._batches_in_row_order(jobs, mine, self.views_per_batch):
                 t1 = time.time()
-                r0 = row[chunk[0]]
+                r0 = chunk[0]
                 refs = [self._slot[jobs[j][0]] for j in chunk]
                 srcs = [[self._slot[s] for s in jobs[j][1]] for j in chunk]
                 eng.patchmatch_device(refs, srcs, self._pm_params(), self.seed_for_stream(),
@@ -373,24 +395,93 @@ class PatchMatchMVS:
                 self.last_timing = eng.timing()
                 per_view = (time.time() - t1) / len(chunk)
                 valid = (conf[r0:r0 + len(chunk)] >= self.min_views).sum(dim=1).tolist()
-                for n, j in enumerate(chunk):
+                for k, j in enumerate(chunk):
                     ref_idx = jobs[j][0]
                     print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: "
-                          f"{int(valid[n]):,} valid pixels ({per_view:.1f}s)")
-        if world > 1:
-            # RCCL gathers the device tensors in place; any other backend (gloo in the tests)
-            # stages through the host
-            direct = torch.distributed.get_backend(self.process_group) == "nccl"
+                          f"{int(valid[k]):,} valid pixels ({per_view:.1f}s)")
+            return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(n)], depth=depth, normal=normal,
+                                 confidence=conf, shape=(H, W))
 
-            def gather(t, width):
-                full = _parallel.allgather_packed(t if direct else t.cpu(), len(jobs), width, self.process_group)
-                return full if direct else full.to(dev)
-            depth, normal, conf = gather(depth, hw), gather(normal, 3 * hw), gather(conf, hw)
-            order = list(range(len(jobs)))
-        else:
-            order = mine
-        return _ResidentMaps(ref_ids=[jobs[j][0] for j in order], depth=depth, normal=normal,
-                             confidence=conf, shape=(H, W))
+        dist = torch.distributed
+        direct = dist.get_backend(self.process_group) == "nccl"
+        per = (n + world - 1) // world                    # rows per rank block (the last block may be short)
+        base = rank * per
+        n_groups = 2 if per >= 2 else 1
+        group_rows = (per + n_groups - 1) // n_groups
+        groups = [(g * group_rows, min((g + 1) * group_rows, per)) for g in range(n_groups)]
+        # job j lives in row j (blocks are contiguous in job order); rows >= n are padding
+        depth = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
+        normal = torch.zeros((world * per, 3 * hw), dtype=torch.float32, device=dev)
+        conf = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
+        maps = [depth, conf] + ([normal] if self.gather_normals else [])      # fusion reads the first two
+        sweep_stream = torch.cuda.Stream(device=dev)
+        comm_stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)                       # the zero fills ran on torch's current stream
+        eng.set_stream(sweep_stream.cuda_stream)
+        works = []
+
+        def gather_group(a, b, swept):
+            """All-gather rows [a, b) of every rank's block; `swept` = event after the launches that wrote them."""
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(swept)
+                for t in maps:
+                    outs = [t[r * per + a: r * per + b] for r in range(world)]
+                    if direct:
+                        works.append(dist.all_gather(outs, t[base + a: base + b], group=self.process_group,
+                                                     async_op=True))
+                    else:                                 # gloo (tests): staged through the host
+                        swept.synchronize()
+                        host = [torch.empty((b - a, t.shape[1]), dtype=torch.float32) for _ in range(world)]
+                        dist.all_gather(host, t[base + a: base + b].cpu(), group=self.process_group)
+                        for r in range(world):
+                            if r != rank:
+                                outs[r].copy_(host[r])
+
+        t1 = time.time()
+        try:
+            done_rows, next_group = 0, 0
+            for chunk in self._batches_in_row_order(jobs, mine, min(self.views_per_batch, group_rows)):
+                # a launch never straddles a group boundary: cut it there
+                pieces, lo = [], 0
+                while lo < len(chunk):
+                    row = chunk[lo] - base
+                    room = groups[min(row // group_rows, n_groups - 1)][1] - row
+                    pieces.append(chunk[lo:lo + room])
+                    lo += room
+                for piece in pieces:
+                    r0 = piece[0]
+                    refs = [self._slot[jobs[j][0]] for j in piece]
+                    srcs = [[self._slot[s] for s in jobs[j][1]] for j in piece]
+                    eng.patchmatch_device(refs, srcs, self._pm_params(), self.seed_for_stream(),
+                                          depth[r0].data_ptr(), normal[r0].data_ptr(), conf[r0].data_ptr())
+                    done_rows = piece[-1] - base + 1
+                    while next_group < n_groups and (done_rows >= groups[next_group][1] or done_rows == len(mine)):
+                        swept = torch.cuda.Event()
+                        swept.record(sweep_stream)
+                        gather_group(*groups[next_group], swept)
+                        next_group += 1
+            while next_group < n_groups:                  # a rank without views still takes part in every collective
+                swept = torch.cuda.Event()
+                swept.record(sweep_stream)
+                gather_group(*groups[next_group], swept)
+                next_group += 1
+            for w in works:
+                w.wait()                                  # torch's current stream waits for the collective
+            eng.sync()
+            self.last_timing = eng.timing()
+            comm_stream.synchronize()
+            torch.cuda.synchronize(dev)
+        finally:
+            eng.set_stream(None)
+        self._streams = (sweep_stream, comm_stream)       # (kept alive until the next call)
+        per_view = (time.time() - t1) / max(len(mine), 1)
+        valid = (conf[:n] >= self.min_views).sum(dim=1).tolist()
+        for j in mine:
+            ref_idx = jobs[j][0]
+            print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: "
+                  f"{int(valid[j]):,} valid pixels ({per_view:.1f}s)")
+        return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(n)], depth=depth[:n], normal=normal[:n],
+                             confidence=conf[:n], shape=(H, W))
 
     def _sweep_extended(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
         """The extended mode (csrc/amvs_extended.hip): the state of ALL views lives in device tensors;
@@ -427,6 +518,9 @@ class PatchMatchMVS:
                 local = t[slots_mine]
                 full = _parallel.allgather_packed(local if direct else local.cpu(), len(jobs), width, self.process_group)
                 t[slots_all] = full if direct else full.to(dev)
+            # the scatter above runs on torch's stream; the engine launches on its own (non-blocking)
+            # stream, which nothing else orders after it
+            torch.cuda.synchronize(dev)
 
         ptrs = (depth.data_ptr(), normal.data_ptr(), cost.data_ptr())
         torch.cuda.synchronize(dev)

@@ -83,6 +83,13 @@ struct amvs_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_tile_rows = 0, last_views_per_launch = 0;
+    // amvs_set_step_tuning: strip rows / resident workgroups per CU by [iteration][0 = propagation, 1 = refinement]
+    // (0 = automatic); iterations beyond the table use its last row
+    std::vector<int> tune_rows, tune_cap;
+    // amvs_set_step_timing: an event behind every sweep launch of the last PatchMatch call
+    bool step_timing = false;
+    std::vector<hipEvent_t> ev_steps;
+    int n_step_events = 0;
     std::vector<hipEvent_t> ev_groups;   // per view group of the last PatchMatch call: init / steps / confidence
     int timing_groups = 0;
     bool timing_pending = false;
@@ -301,12 +308,13 @@ int default_views_per_launch(const amvs_ctx *c, int n_ref)
 // -- the winners are the heights whose wave count is just below a whole number of generations
 // (or at least 3/4 of one).  Hence: among the heights up to `tall`, the best product of the last
 // generation's fill and the strip's useful fraction rows / (rows + patch - 1).
-int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap, bool fast = false)
+int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap, bool fast = false,
+                   int wg_cap = 0)
 {
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
-    const long long slots = (long long)c->n_cu * (fast ? amvs::step_fast_waves_per_cu(patch, n_src)
-                                                       : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr));
+    const long long slots = (long long)c->n_cu * (fast ? amvs::step_fast_waves_per_cu(patch, n_src, wg_cap)
+                                                       : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr, wg_cap));
     int tall = 4 * patch - 4 > 12 ? 4 * patch - 4 : 12;
     if (c->W > 2048) tall = tall * 2 / 3 > 8 ? tall * 2 / 3 : 8;
     if (tall > cap) tall = cap;
@@ -358,15 +366,16 @@ amvs::StepArgs base_args(const amvs_ctx *c, int patch, int n_jobs, int TH)
 }
 
 // depth buffer `cur_d` is read and cur_d^1 written on every step; cost lives in d_cost[0] and is
-// updated in place; normals: a propagation step reads buffer cur_n and writes cur_n^1, every other
-// mode works in place on cur_n
-void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur_d, int cur_n)
+// updated in place; normals: both buffers, the sign bit of the state depths names each pixel's
+// current one (StepArgs::nbuf).  `tagged`: d_in is a state map (its depths carry that bit).
+void set_io(amvs::StepArgs &a, const amvs_ctx *c, int cur_d, bool tagged = true)
 {
     a.d_in = c->d_depth[cur_d];
     a.d_out = c->d_depth[cur_d ^ 1];
     a.cost = c->d_cost[0];
-    a.n_in = c->d_normal[cur_n];
-    a.n_out = a.mode == amvs::MODE_PROP ? c->d_normal[cur_n ^ 1] : c->d_normal[cur_n];
+    a.nbuf[0] = c->d_normal[0];
+    a.nbuf[1] = c->d_normal[1];
+    a.depth_mask = tagged ? 0x7FFFFFFFu : 0xFFFFFFFFu;
 }
 
 void resolve_timing(amvs_ctx *c)
@@ -396,12 +405,35 @@ void resolve_timing(amvs_ctx *c)
     }
 }
 
+// Launch shape of one sweep step.  The gathers of an early iteration are scattered over the whole
+// depth range (every pixel perturbs its depth by up to depth_range / 2^it), those of a late one are
+// coherent, so the best strip height / residency differ by iteration; measured table: DESIGN.md
+// section 5 (round 3).  An explicit amvs_pm_params.tile_rows, then amvs_set_step_tuning, override it.
+struct StepShape { int rows, wg_cap; };
+
+StepShape step_shape(const amvs_ctx *c, const amvs_pm_params *p, int n_src, int n_jobs, int iter, bool refine, bool fast,
+                     int default_rows)
+{
+    StepShape s{default_rows, 0};
+    const size_t idx = (size_t)2 * (size_t)iter + (refine ? 1 : 0);
+    const size_t last = c->tune_rows.size() >= 2 ? c->tune_rows.size() - 2 + (refine ? 1 : 0) : 0;
+    int rows = 0, cap = 0;
+    if (!c->tune_rows.empty()) rows = c->tune_rows[idx < c->tune_rows.size() ? idx : last];
+    if (!c->tune_cap.empty()) cap = c->tune_cap[idx < c->tune_cap.size() ? idx : last];
+    if (cap > 0) s.wg_cap = cap;
+    if (p->tile_rows > 0) return s;                       // the caller fixed the strip height
+    if (rows > 0) s.rows = rows;
+    else if (cap > 0) s.rows = pick_tile_rows(c, p->patch_size, n_src, n_jobs, 0, 1 << 20, fast, cap);
+    return s;
+}
+
 // The sweep schedule of one PatchMatch call as a list of launches (the same for every view).
 struct SchedStep {
     int mode, oy, ox;
     float depth_range, normal_range;
     unsigned draw;
-    int flip_d, flip_n;                  // buffers ping-ponged by the step (set_io)
+    int flip_d;                          // depth buffers ping-ponged by the step (set_io)
+    int iter;
 };
 
 std::vector<SchedStep> build_schedule(const amvs_pm_params *p)
@@ -412,12 +444,12 @@ std::vector<SchedStep> build_schedule(const amvs_pm_params *p)
         // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
         const int sgn = (it % 2 == 0) ? 1 : -1;
         for (int k = 0; k < 2; ++k)
-            v.push_back(SchedStep{amvs::MODE_PROP, k == 0 ? sgn : 0, k == 0 ? 0 : sgn, 0.f, 0.f, 0u, 1, 1});
+            v.push_back(SchedStep{amvs::MODE_PROP, k == 0 ? sgn : 0, k == 0 ? 0 : sgn, 0.f, 0.f, 0u, 1, it});
         // _random_refinement (mvs_patchmatch.py:459-491): ranges formed in double, cast once
         const float dr = (float)(((double)p->depth_max - (double)p->depth_min) * std::pow(0.5, it));
         const float nr = (float)(0.5 * std::pow(0.5, it));
         for (int s = 0; s < p->num_samples; ++s)
-            v.push_back(SchedStep{amvs::MODE_REFINE, 0, 0, dr, nr, (unsigned)(1 + it * p->num_samples + s), 1, 0});
+            v.push_back(SchedStep{amvs::MODE_REFINE, 0, 0, dr, nr, (unsigned)(1 + it * p->num_samples + s), 1, it});
     }
     return v;
 }
@@ -443,6 +475,20 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
                        ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0)
                        : pick_band_rows(c, p->patch_size, n_src, vpl, fast != 0);
     c->last_tile_rows = TH;
+    // launch shape of every step: strip rows and resident workgroups per CU (step_shape)
+    std::vector<StepShape> shapes(sched.size());
+    for (size_t i = 0; i < sched.size(); ++i) {
+        shapes[i] = band_major ? StepShape{TH, 0}
+                               : step_shape(c, p, n_src, vpl, sched[i].iter, sched[i].mode == amvs::MODE_REFINE, fast != 0, TH);
+        c->last_tile_rows = shapes[i].rows;
+    }
+    const int n_steps_timed = c->step_timing ? (int)sched.size() * ((n_ref + vpl - 1) / vpl) : 0;
+    while ((int)c->ev_steps.size() < n_steps_timed + (n_ref + vpl - 1) / vpl) {
+        hipEvent_t ev;
+        HIPCHK(c, hipEventCreate(&ev));
+        c->ev_steps.push_back(ev);
+    }
+    c->n_step_events = 0;
     const int n_groups = (n_ref + vpl - 1) / vpl;
     // events: [0] start, then per group: after init, after steps, after confidence
     while ((int)c->ev_groups.size() < 3 * n_groups) {
@@ -460,21 +506,30 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;
-        int cur = 0, cur_n = 0;
+        int cur = 0;
         // initialisation (mvs_patchmatch.py:268-284)
         HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
-                                    c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
+                                    c->d_depth[cur], c->d_normal[0], c->d_cost[0], c->stream));
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g], c->stream));
-        for (const SchedStep &st : sched) {
+        if (c->step_timing) HIPCHK(c, hipEventRecord(c->ev_steps[c->n_step_events++], c->stream));
+        for (size_t i = 0; i < sched.size(); ++i) {
+            const SchedStep &st = sched[i];
             apply_step(a, st);
-            set_io(a, c, cur, cur_n);
+            a.TH = shapes[i].rows;
+            a.tiles_y = (c->H + a.TH - 1) / a.TH;
+            a.wg_cap = shapes[i].wg_cap;
+            set_io(a, c, cur);
             HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
-            cur ^= st.flip_d; cur_n ^= st.flip_n; ++launches;
+            if (c->step_timing) HIPCHK(c, hipEventRecord(c->ev_steps[c->n_step_events++], c->stream));
+            cur ^= st.flip_d; ++launches;
         }
+        a.TH = TH;
+        a.tiles_y = (c->H + TH - 1) / TH;
+        a.wg_cap = 0;
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 1], c->stream));
         // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
         a.mode = amvs::MODE_CONF;
-        set_io(a, c, cur, cur_n);
+        set_io(a, c, cur);
         a.aux = conf_dev ? (float *)conf_dev : c->d_aux;
         HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
@@ -554,9 +609,9 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     all.s_lds = c->split_sample_lds;
     all.s_tiles_x = (c->W + 63) / 64;
     all.s_tiles_y = (c->H + s_TH - 1) / s_TH;
-    int cur = 0, cur_n = 0;
+    int cur = 0;
     HIPCHK(c, amvs::launch_init(all.jobs, n_ref, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
-                                c->d_depth[cur], c->d_normal[cur_n], c->d_cost[0], c->stream));
+                                c->d_depth[cur], c->d_normal[0], c->d_cost[0], c->stream));
     HIPCHK(c, hipEventRecord(c->ev_groups[0], c->stream));
     HIPCHK(c, hipEventRecord(ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(s_smp, ev_fork, 0));
@@ -569,7 +624,7 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
             a.n_jobs = nj;
             a.jobs = c->d_jobs + j0;
             apply_step(a, st);
-            set_io(a, c, cur, cur_n);
+            set_io(a, c, cur);
             if (!first) HIPCHK(c, hipStreamWaitEvent(s_smp, ev_windowed[g], 0));
             HIPCHK(c, amvs::launch_sample_fast(n_src, a, s_smp));
             HIPCHK(c, hipEventRecord(ev_sampled[g], s_smp));
@@ -579,14 +634,14 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
             HIPCHK(c, hipEventRecord(ev_windowed[g], s_win));
         }
         first = false;
-        cur ^= st.flip_d; cur_n ^= st.flip_n;
+        cur ^= st.flip_d;
     }
     // the window stream is in order, so its last event covers every group
     if (!sched.empty()) HIPCHK(c, hipStreamWaitEvent(c->stream, ev_windowed[G - 1], 0));
     HIPCHK(c, hipEventRecord(c->ev_groups[1], c->stream));
     // _compute_confidence (mvs_patchmatch.py:493-534): one fused launch over the whole batch
     all.mode = amvs::MODE_CONF;
-    set_io(all, c, cur, cur_n);
+    set_io(all, c, cur);
     all.aux = conf_dev ? (float *)conf_dev : c->d_aux;
     HIPCHK(c, amvs::launch_step(p->patch_size, n_src, all, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_groups[2], c->stream));
@@ -617,7 +672,7 @@ int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64, fast != 0));
     o.a.fast = fast;
     o.a.mode = amvs::MODE_EVAL;
-    set_io(o.a, c, 0, 0);
+    set_io(o.a, c, 0, false);                   // caller-supplied depth maps: no tag to strip
     return AMVS_OK;
 }
 
@@ -629,10 +684,13 @@ int upload_state(amvs_ctx *c, size_t hw, const float *depth, const float *normal
     return AMVS_OK;
 }
 
-int download_state(amvs_ctx *c, size_t hw, int dbuf, int nbuf, float *depth, float *normal, float *cost)
+// state of slot 0 after a single step (tagged depths in d_depth[dbuf]) -> plain host arrays
+int download_state(amvs_ctx *c, size_t hw, int dbuf, float *depth, float *normal, float *cost)
 {
+    HIPCHK(c, amvs::launch_resolve_state(c->d_jobs, 1, (long long)hw, c->d_depth[dbuf], c->d_normal[0], c->d_normal[1],
+                                         nullptr, nullptr, 0, c->stream));
     HIPCHK(c, hipMemcpyAsync(depth, c->d_depth[dbuf], 4 * hw, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal, c->d_normal[nbuf], 12 * hw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal, c->d_normal[0], 12 * hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(cost, c->d_cost[0], 4 * hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMVS_OK;
@@ -737,6 +795,7 @@ int amvs_destroy(amvs_ctx *c)
         if (kv.second.maps) (void)hipFree(kv.second.maps);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->ev_groups) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ev_steps) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return AMVS_OK;
@@ -882,13 +941,15 @@ int amvs_set_view_device(amvs_ctx *c, int view, const void *gray_device, const f
     return set_view_common(c, view, gray_device, R, t, hipMemcpyDeviceToDevice);
 }
 
-// The sweep of a batch: state in the context's buffers (final depth in d_depth[*cur], normals in
-// d_normal[*cur_n]), confidence into `conf_dev` (NULL: the context's d_aux).
+// The sweep of a batch: state in the context's buffers (final tagged depth in d_depth[*cur], normals
+// in d_normal[0 / 1] as the tags say), confidence into `conf_dev` (NULL: the context's d_aux).
 static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
-                           const amvs_pm_params *p, uint64_t seed, void *conf_dev, int *cur_out, int *cur_n_out)
+                           const amvs_pm_params *p, uint64_t seed, void *conf_dev, int *cur_out)
 {
     if (!p || !ref_ids || !src_ids || n_ref <= 0) return fail(c, AMVS_EINVAL, "NULL argument / empty batch");
     if (p->num_iterations < 0 || p->num_samples < 0) return fail(c, AMVS_EINVAL, "negative iteration count");
+    // (the reference takes log(depth_min), mvs_patchmatch.py:269; the state maps use the depths' sign bit)
+    if (!(p->depth_min > 0.0f) || !(p->depth_max >= p->depth_min)) return fail(c, AMVS_EINVAL, "need 0 < depth_min <= depth_max");
     int rc = bind_device(c);
     if (rc) return rc;
     if ((rc = check_patch_src(c, p->patch_size, n_src))) return rc;
@@ -904,17 +965,17 @@ static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     resolve_timing(c);
     c->timing = amvs_timing{};
     const std::vector<SchedStep> sched = build_schedule(p);
-    int cur = 0, cur_n = 0;
-    for (const SchedStep &st : sched) { cur ^= st.flip_d; cur_n ^= st.flip_n; }   // final buffers
+    int cur = 0;
+    for (const SchedStep &st : sched) cur ^= st.flip_d;                           // final depth buffer
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (p->schedule == AMVS_SCHEDULE_SPLIT) {
         if ((rc = run_split_schedule(c, n_ref, n_src, p, seed, sched, conf_dev))) return rc;
     } else {
         if ((rc = run_fused_schedule(c, n_ref, n_src, p, seed, fast, sched, conf_dev))) return rc;
     }
-    // every group ran the same schedule, so the final buffers (cur, cur_n) are the same for all
+    // every group ran the same schedule, so the final depth buffer is the same for all
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    *cur_out = cur; *cur_n_out = cur_n;
+    *cur_out = cur;
     c->timing.pixel_hypotheses =
         (int64_t)n_ref * (int64_t)hw * p->num_iterations * (2 + p->num_samples);
     c->timing_pending = true;
@@ -927,12 +988,13 @@ int amvs_patchmatch_device(amvs_ctx *c, int n_ref, const int *ref_ids, const int
 {
     if (!c) return AMVS_EINVAL;
     if (!depth_dev || !normal_dev || !conf_dev) return fail(c, AMVS_EINVAL, "NULL output");
-    int cur = 0, cur_n = 0;
-    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, conf_dev, &cur, &cur_n);
+    int cur = 0;
+    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, conf_dev, &cur);
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
-    HIPCHK(c, hipMemcpyAsync(depth_dev, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal_dev, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToDevice, c->stream));
+    // untagged depths and the current normal of every pixel straight into the caller's arrays
+    HIPCHK(c, amvs::launch_resolve_state(c->d_jobs, n_ref, (long long)hw, c->d_depth[cur], c->d_normal[0], c->d_normal[1],
+                                         (float *)depth_dev, (float *)normal_dev, 0, c->stream));
     return AMVS_OK;
 }
 
@@ -944,12 +1006,14 @@ int amvs_patchmatch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_i
 {
     if (!c) return AMVS_EINVAL;
     if (!depth_out || !normal_out || !conf_out || n_ref <= 0) return fail(c, AMVS_EINVAL, "NULL output");
-    int cur = 0, cur_n = 0;
-    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, nullptr, &cur, &cur_n);
+    int cur = 0;
+    int rc = patchmatch_core(c, n_ref, ref_ids, src_ids, n_src, p, seed, nullptr, &cur);
     if (rc) return rc;
     const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, amvs::launch_resolve_state(c->d_jobs, n_ref, (long long)hw, c->d_depth[cur], c->d_normal[0], c->d_normal[1],
+                                         nullptr, nullptr, 0, c->stream));
     HIPCHK(c, hipMemcpyAsync(depth_out, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(normal_out, c->d_normal[cur_n], 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(normal_out, c->d_normal[0], 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
@@ -998,6 +1062,52 @@ int amvs_set_split_tuning(amvs_ctx *c, int groups, int sample_rows, int sample_l
     if (groups < 0 || groups > 8 || sample_rows < 0 || sample_lds_bytes < 0 || sample_lds_bytes > 64 * 1024)
         return fail(c, AMVS_EINVAL, "split tuning out of range");
     c->split_groups = groups; c->split_sample_rows = sample_rows; c->split_sample_lds = sample_lds_bytes;
+    return AMVS_OK;
+}
+
+int amvs_set_step_tuning(amvs_ctx *c, int n_iterations, const int32_t *tile_rows, const int32_t *wgs_per_cu)
+{
+    if (!c) return AMVS_EINVAL;
+    if (n_iterations < 0 || (n_iterations > 0 && !tile_rows && !wgs_per_cu)) return fail(c, AMVS_EINVAL, "bad step tuning table");
+    c->tune_rows.clear(); c->tune_cap.clear();
+    for (int i = 0; i < 2 * n_iterations; ++i) {
+        const int r = tile_rows ? tile_rows[i] : 0, w = wgs_per_cu ? wgs_per_cu[i] : 0;
+        if (r < 0 || r > (1 << 20) || w < 0 || w > 8) {
+            c->tune_rows.clear(); c->tune_cap.clear();
+            return fail(c, AMVS_EINVAL, "step tuning: rows >= 0, workgroups per CU in 0..8");
+        }
+        c->tune_rows.push_back(r); c->tune_cap.push_back(w);
+    }
+    return AMVS_OK;
+}
+
+int amvs_set_step_timing(amvs_ctx *c, int enable)
+{
+    if (!c) return AMVS_EINVAL;
+    c->step_timing = enable != 0;
+    c->n_step_events = 0;
+    return AMVS_OK;
+}
+
+int amvs_get_step_times(amvs_ctx *c, float *ms_out, int capacity, int *n_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!n_out || (capacity > 0 && !ms_out)) return fail(c, AMVS_EINVAL, "NULL argument");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // events: per view group one start event followed by one per launch
+    const int groups = c->timing_groups > 0 ? c->timing_groups : 1;
+    const int per_group = c->n_step_events / groups;          // 1 + launches
+    int n = 0;
+    for (int g = 0; g < groups && per_group > 1; ++g)
+        for (int i = 1; i < per_group; ++i, ++n) {
+            if (n >= capacity) continue;
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev_steps[g * per_group + i - 1], c->ev_steps[g * per_group + i]));
+            ms_out[n] = ms;
+        }
+    *n_out = n;
     return AMVS_OK;
 }
 
@@ -1387,7 +1497,7 @@ int amvs_confidence(amvs_ctx *c, int ref, const int *src_ids, int n_src, int pat
     if (!depth_in || !conf_out) return fail(c, AMVS_EINVAL, "NULL argument");
     if ((rc = upload_state(c, o.hw, depth_in, nullptr, nullptr))) return rc;
     o.a.mode = amvs::MODE_CONF;
-    set_io(o.a, c, 0, 0);
+    set_io(o.a, c, 0, false);
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
     HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * o.hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1403,10 +1513,10 @@ int amvs_propagate_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int
     if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
     if ((rc = upload_state(c, o.hw, depth, normal, cost))) return rc;
     o.a.mode = amvs::MODE_PROP;
-    set_io(o.a, c, 0, 0);
+    set_io(o.a, c, 0);
     o.a.oy = oy; o.a.ox = ox; o.a.depth_min = depth_min;
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
-    return download_state(c, o.hw, 1, 1, depth, normal, cost);
+    return download_state(c, o.hw, 1, depth, normal, cost);
 }
 
 int amvs_refine_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patch_size, float *depth,
@@ -1423,12 +1533,12 @@ int amvs_refine_step(amvs_ctx *c, int ref, const int *src_ids, int n_src, int pa
                              hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     o.a.mode = amvs::MODE_REFINE;
-    set_io(o.a, c, 0, 0);
+    set_io(o.a, c, 0);
     o.a.seed = seed; o.a.draw = draw;
     o.a.depth_range = depth_range; o.a.normal_range = normal_range;
     o.a.depth_min = depth_min; o.a.depth_max = depth_max;
     HIPCHK(c, amvs::launch_step(patch_size, n_src, o.a, c->stream));
-    return download_state(c, o.hw, 1, 0, depth, normal, cost);
+    return download_state(c, o.hw, 1, depth, normal, cost);
 }
 
 int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_depth_scale,
@@ -1448,7 +1558,7 @@ int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_
     const size_t hw = (size_t)c->H * c->W;
     HIPCHK(c, amvs::launch_init(c->d_jobs, 1, (long long)hw, seed, log_depth_scale, log_depth_min,
                                 c->d_depth[0], c->d_normal[0], c->d_cost[0], c->stream));
-    return download_state(c, hw, 0, 0, depth, normal, cost);
+    return download_state(c, hw, 0, depth, normal, cost);
 }
 
 int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float *var_out)

@@ -56,13 +56,20 @@ template <int K, int S> struct Hist {
     typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;
 };
 
+// Depth state maps carry, in the sign bit, the normal buffer that holds the pixel's current normal
+// (StepArgs::nbuf); depths themselves are positive.
+AMVS_DEV float depth_untag(float d, unsigned mask) { return __uint_as_float(__float_as_uint(d) & mask); }
+AMVS_DEV unsigned depth_buffer(float d) { return __float_as_uint(d) >> 31; }
+AMVS_DEV float depth_tag(float d, unsigned buffer) { return __uint_as_float(__float_as_uint(d) | (buffer << 31)); }
+
 // Normal update of `n` queued refinement winners (entries head .. head+n-1 of the ring `nq`), one
-// per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).
-AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *n_out, float normal_range)
+// per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).  Entry: pixel
+// index with the winner's normal buffer in bit 31, hash.
+AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, float normal_range)
 {
     if (lane < n) {
         const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
-        float *np = n_out + 3ll * (int)e.x;
+        float *np = ((e.x >> 31) ? nbuf1 : nbuf0) + 3ll * (int)(e.x & 0x7FFFFFFFu);
         float g0, g1, g2;
         rng_normals3(e.y, g0, g1, g2);
         float cn0 = np[0] + g0 * normal_range;
@@ -70,6 +77,33 @@ AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *
         float cn2 = np[2] + g2 * normal_range;
         normalize3(cn0, cn1, cn2);
         np[0] = cn0; np[1] = cn1; np[2] = cn2;
+    }
+}
+
+// Propagation winners (mvs_patchmatch.py:452-455), queued like the refinement winners and moved 64 at
+// a time: pixel pc takes the pre-step normal of its neighbour pn (zero outside the image, F.pad
+// :431-442) into the buffer it does not currently use.  Entry: x = pc | its current buffer << 31,
+// y = pn | neighbour inside the image << 30 | neighbour's buffer << 31 (pixel indices are below 2^29).
+// Nothing writes a neighbour's CURRENT normal during a propagation launch and nothing reads the
+// buffer a winner writes (StepArgs::nbuf), so the move may happen any time before the launch ends.
+AMVS_DEV uint2 propagate_entry(int pc, unsigned buf_c, int pn, bool inb_c, unsigned buf_n)
+{
+    return make_uint2((unsigned)pc | (buf_c << 31), (unsigned)pn | ((inb_c ? 1u : 0u) << 30) | (buf_n << 31));
+}
+
+AMVS_DEV void propagate_normals(const uint2 *nq, int head, int n, int lane, float *nbuf0, float *nbuf1)
+{
+    if (lane < n) {
+        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
+        const int pc = (int)(e.x & 0x7FFFFFFFu), pn = (int)(e.y & 0x3FFFFFFFu);
+        const bool inb_c = (e.y >> 30) & 1u;
+        // (three consecutive dwords each way: hipcc merges them into one dwordx3 access)
+        const float *src = ((e.y >> 31) ? nbuf1 : nbuf0) + 3ll * pn;
+        const float t0 = src[0], t1 = src[1], t2 = src[2];
+        float *dst = ((e.x >> 31) ? nbuf0 : nbuf1) + 3ll * pc;
+        dst[0] = inb_c ? t0 : 0.0f;
+        dst[1] = inb_c ? t1 : 0.0f;
+        dst[2] = inb_c ? t2 : 0.0f;
     }
 }
 

@@ -61,15 +61,22 @@ struct StepArgs : StepArgsBase {
     // one thin row front of every image instead of a tall band of a few.
     int band_major;
     // State [slot][H*W] (normals [slot][H*W*3]).  Depth is ping-ponged on every step (halo pixels
-    // of other strips read the pre-step map).  Cost and normals are only ever touched at a lane's
-    // own pixel: cost is updated in place; normals are updated in place by refinement steps (only
-    // where the candidate wins) and ping-ponged by propagation steps (the candidate is the
-    // NEIGHBOUR's pre-step normal).
+    // of other strips read the pre-step map).  Cost is only ever touched at a lane's own pixel and
+    // updated in place.  Normals never enter the cost (mvs_patchmatch.py:323-390 ignores them), so
+    // they are moved only where a candidate WINS: they live in two buffers nbuf[0], nbuf[1], and the
+    // SIGN BIT of a pixel's depth in the state maps names the buffer that holds its current normal
+    // (depths are >= depth_min > 0, so the bit is free; it travels with the depth ping-pong at no
+    // cost).  A propagation winner p (candidate = the NEIGHBOUR q's pre-step normal, :452-455) reads
+    // nbuf[sign d_in[q]][q], writes the buffer p does not currently use and stores its new depth with
+    // the flipped sign; a refinement winner updates its current buffer in place; losers touch no
+    // normal.  No pixel reads a location another pixel writes in the same launch.  `depth_mask` strips
+    // the tag from every depth read: 0x7FFFFFFF for state maps, 0xFFFFFFFF for caller-supplied maps
+    // (amvs_eval_cost / amvs_confidence).  launch_resolve_state turns tagged state into plain maps.
     const float *d_in;
     float *d_out;
     float *cost;
-    const float *n_in;                       // MODE_PROP only
-    float *n_out;                            // MODE_PROP: the other buffer; MODE_REFINE: the current one
+    float *nbuf[2];
+    unsigned depth_mask;
     float *aux;                              // MODE_EVAL: cost map, MODE_CONF: confidence
     const Job *jobs;
     int mode, oy, ox;
@@ -83,7 +90,12 @@ struct StepArgs : StepArgsBase {
     int half;                                // patch_size / 2
     int s_TH, s_tiles_x, s_tiles_y;
     int s_lds;                               // unused dynamic LDS per sampling workgroup (occupancy cap); 0 = default
+    // Resident workgroups per CU of this sweep launch (enforced through unused dynamic LDS: 160 KiB /
+    // wg_cap per workgroup); 0 = the default of AMVS_DEFAULT_WGS_PER_CU.  Performance only.
+    int wg_cap;
 };
+
+#define AMVS_DEFAULT_WGS_PER_CU 4
 
 struct SweepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs, D;
@@ -100,7 +112,7 @@ bool knn_supported(int k);
 hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st,
                              bool points_on_device = false);
 int strip_out_width(int K);
-int step_waves_per_cu(int K, int S, bool u8);
+int step_waves_per_cu(int K, int S, bool u8, int wg_cap = 0);      // resident waves per CU under the cap (0 = default)
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
 // amvs_kernels_fast.hip: the same steps in the fast arithmetic (a.fast != 0; launch_step /
@@ -108,7 +120,7 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st);
 hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st);      // split schedule, first half
 hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st);
-int step_fast_waves_per_cu(int K, int S);
+int step_fast_waves_per_cu(int K, int S, int wg_cap = 0);
 // test hook: per-source samples [S][H*W] and validity bits [H*W] of job 0 at the depth map a.d_in;
 // a.TH carries k/2, a.mode selects the bounds (MODE_EVAL patch bounds, MODE_CONF image bounds,
 // MODE_EVAL + 100 depth test only = plane sweep)
@@ -132,6 +144,11 @@ hipError_t launch_pack_pairs(const float *img, int H, int W, uint16_t *pairs, in
 hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long long seed,
                        float log_scale, float log_min, float *depth, float *normal, float *cost,
                        hipStream_t st);
+// Tagged state (StepArgs::nbuf) -> plain maps for the slots of `jobs`: depth_out[p] = |depth[p]|,
+// normal_out[p] = nbuf[sign depth[p]][p].  Outputs are indexed by (slot - out_slot0); with depth_out ==
+// NULL the state is resolved in place (depth untagged, current normals gathered into nbuf0).
+hipError_t launch_resolve_state(const Job *jobs, int n_jobs, long long HW, float *depth, float *nbuf0, const float *nbuf1,
+                                float *depth_out, float *normal_out, long long out_slot0, hipStream_t st);
 hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st);
 hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw, long long n,
                            float *u_out, float *n_out, hipStream_t st);

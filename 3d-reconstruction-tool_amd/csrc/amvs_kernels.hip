@@ -317,10 +317,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 #define AMVS_REF_CODE(i) (ref_pairs[i])
 #endif
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
-    const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
     float *cost_io = a.cost + job->slot * HW;          // read and (where the candidate wins) written
-    float *n_out = a.n_out + job->slot * HW * 3;
+    float *nbuf0 = a.nbuf[0] + job->slot * HW * 3, *nbuf1 = a.nbuf[1] + job->slot * HW * 3;
     float *__restrict__ aux = a.aux + job->slot * HW;
 
     const StreamKey key = stream_key(a.seed, job->stream_view, a.draw);
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
-        float dc = inb ? d_raw : a.depth_min;
+        float dc = inb ? depth_untag(d_raw, a.depth_mask) : a.depth_min;
         // depth + (rand*2-1)*range, clamped (mvs_patchmatch.py:471-472)
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
         {
@@ -411,7 +410,16 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = outl ? yc * W + xc : 0;
-        const float oldd = d_in[pc], oldc = cost_io[pc];
+        const float oldd_tagged = d_in[pc], oldc = cost_io[pc];
+        const float oldd = depth_untag(oldd_tagged, a.depth_mask);
+        const unsigned buf_c = depth_buffer(oldd_tagged);     // where this pixel's current normal lives
+        // propagation: the neighbour the candidate was pulled from (requested with the other state
+        // loads: behind the selection it would expose a memory round trip in every row).  Lanes
+        // without an output pixel have pc = 0: they must not form pc + noff, which lies BEFORE the map
+        // for the negative offsets of odd iterations.
+        const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
+        const int pn = (outl & inb_c) ? pc + noff : 0;
+        const float nb_tagged = mode == MODE_PROP ? d_in[pn] : 0.0f;
         // the centre pixel was sampled by lane+HALF, HALF rows ago
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);     // low S bits: row r-HALF
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
@@ -501,25 +509,28 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         if (better) cost_io[pc] = newc;
         if (mode == MODE_PROP) {
             // candidate = the neighbour's pre-step state; out-of-image neighbour: depth_min and a
-            // zero normal (F.pad, :431-442).  Normals are ping-ponged on these steps.
-            const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-            const int pn = inb_c ? pc + noff : 0;
-            const int ps = better ? pn : pc;              // whose normal this pixel takes
-            const float nb_d = d_in[pn];
-            float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
-            const bool zero = better & !inb_c;
-            if (act) {
-                d_out[pc] = better ? (inb_c ? nb_d : a.depth_min) : oldd;
-                n_out[3 * pc] = zero ? 0.0f : t0;
-                n_out[3 * pc + 1] = zero ? 0.0f : t1;
-                n_out[3 * pc + 2] = zero ? 0.0f : t2;
+            // zero normal (F.pad, :431-442).  Only the winners' normals move (StepArgs::nbuf).
+            // out-of-image neighbour: depth_min and a zero normal (F.pad, :431-442).  Only the winners'
+            // normals move (StepArgs::nbuf), queued and moved 64 at a time like the refinement winners'.
+            const float nb_d = depth_untag(nb_tagged, a.depth_mask);
+            if (act) d_out[pc] = better ? depth_tag(inb_c ? nb_d : a.depth_min, buf_c ^ 1u) : oldd_tagged;
+            const unsigned long long won = __ballot(better);
+            if (won != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, pn, inb_c, depth_buffer(nb_tagged));
+                q_tail += __popcll(won);
+                if (q_tail - q_head >= AMVS_WAVE) {
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1);
+                    q_head += AMVS_WAVE;
+                }
             }
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            if (act) d_out[pc] = better ? d : oldd;
+            if (act) d_out[pc] = better ? depth_tag(d, buf_c) : oldd_tagged;
             // The winners' normals (normalize(normal + randn*range), mvs_patchmatch.py:475-476) are
             // not updated here: a row has ~3 winners among its 58 pixels, yet the ~150-instruction
             // update would run for the whole wave on almost every row.  Winners are queued in LDS
@@ -529,19 +540,20 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc | (buf_c << 31), h0c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range);
                     q_head += AMVS_WAVE;
                 }
             }
         }
     }
-    if (mode == MODE_REFINE) {
+    if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            refine_normals(nq, q_head, n, lane, n_out, a.normal_range);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1);
             q_head += n;
         }
     }
@@ -876,7 +888,35 @@ __global__ __launch_bounds__(256) void pm_init_kernel(const Job *__restrict__ jo
         normal[3 * (base + i)] = nx;
         normal[3 * (base + i) + 1] = ny;
         normal[3 * (base + i) + 2] = nz;
-        cost[base + i] = __builtin_inff();
+        cost[base + i] = __builtin_inff();      // (depth > 0: the normal just written, buffer 0, is the current one)
+    }
+}
+
+// tagged state -> plain maps (launch_resolve_state, StepArgs::nbuf)
+__global__ __launch_bounds__(256) void resolve_state_kernel(const Job *__restrict__ jobs, long long HW, float *depth,
+                                                            float *nbuf0, const float *__restrict__ nbuf1,
+                                                            float *depth_out, float *normal_out, long long out_slot0)
+{
+    const JobCP job = (JobCP)(jobs + blockIdx.y);
+    const long long base = job->slot * HW;
+    const long long obase = (job->slot - out_slot0) * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float d = depth[base + i];
+        const unsigned buf = depth_buffer(d);
+        const float da = depth_untag(d, 0x7FFFFFFFu);
+        if (depth_out) {
+            const float *src = (buf ? nbuf1 : nbuf0) + 3 * (base + i);
+            const float t0 = src[0], t1 = src[1], t2 = src[2];
+            depth_out[obase + i] = da;
+            normal_out[3 * (obase + i)] = t0; normal_out[3 * (obase + i) + 1] = t1; normal_out[3 * (obase + i) + 2] = t2;
+        } else if (buf) {
+            depth[base + i] = da;
+            const float *src = nbuf1 + 3 * (base + i);
+            const float t0 = src[0], t1 = src[1], t2 = src[2];
+            float *dst = nbuf0 + 3 * (base + i);
+            dst[0] = t0; dst[1] = t1; dst[2] = t2;
+        }
     }
 }
 
@@ -927,19 +967,17 @@ hipError_t launch_lean_math_check(unsigned long long *mismatch, hipStream_t st)
 // bound by the CU's L1 line rate for scattered gathers, not by latency, so waves beyond ~16 per CU
 // only widen the band of source rows an XCD touches at once (more L2 misses); measured on the fast
 // kernel 24 waves 0.897 ms, 20: 0.822, 16: 0.814, 12: 0.856 (amvs_kernels_fast.hip).
-#ifndef AMVS_MAX_WGS_PER_CU
-#define AMVS_MAX_WGS_PER_CU 4
-#endif
+// (StepArgs::wg_cap; 0 = AMVS_DEFAULT_WGS_PER_CU)
 template <auto Kern>
-static unsigned step_extra_lds()
+static unsigned step_extra_lds(int wg_cap)
 {
-    static const unsigned extra = [] {
+    static const unsigned static_lds = [] {
         hipFuncAttributes at{};
-        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(Kern)) != hipSuccess) return 0u;
-        const unsigned share = 160u * 1024u / AMVS_MAX_WGS_PER_CU;
-        return (unsigned)at.sharedSizeBytes < share ? share - (unsigned)at.sharedSizeBytes : 0u;
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(Kern)) != hipSuccess) return ~0u;
+        return (unsigned)at.sharedSizeBytes;
     }();
-    return extra;
+    const unsigned share = 160u * 1024u / (unsigned)(wg_cap > 0 ? wg_cap : AMVS_DEFAULT_WGS_PER_CU);
+    return static_lds < share ? share - static_lds : 0u;
 }
 
 template <int K, int S>
@@ -948,7 +986,7 @@ static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
     const int nwg = (nblk + AMVS_WG_WAVES - 1) / AMVS_WG_WAVES;
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
 #define AMVS_LAUNCH_STEP(U8, M) \
-    hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, (step_extra_lds<&pm_step_kernel<K, S, U8, M>>()), st, a)
+    hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, (step_extra_lds<&pm_step_kernel<K, S, U8, M>>(a.wg_cap)), st, a)
     if (a.pairs) {
         if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(true, MODE_REFINE);
         else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(true, MODE_PROP);
@@ -983,26 +1021,26 @@ static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
     }
 
 template <int K, int S>
-static int step_occupancy_ks(bool u8)
+static int step_occupancy_ks(bool u8, int wg_cap)
 {
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
     hipError_t e = u8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, true, MODE_REFINE>, TPB,
-                                                                     step_extra_lds<&pm_step_kernel<K, S, true, MODE_REFINE>>())
+                                                                     step_extra_lds<&pm_step_kernel<K, S, true, MODE_REFINE>>(wg_cap))
                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_kernel<K, S, false, MODE_REFINE>, TPB,
-                                                                     step_extra_lds<&pm_step_kernel<K, S, false, MODE_REFINE>>());
+                                                                     step_extra_lds<&pm_step_kernel<K, S, false, MODE_REFINE>>(wg_cap));
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
 // resident waves per CU of the sweep kernel (register-limited)
-int step_waves_per_cu(int K, int S, bool u8)
+int step_waves_per_cu(int K, int S, bool u8, int wg_cap)
 {
     switch (K) {
-    case 3: AMVS_FOR_S(3, step_occupancy_ks, u8)
-    case 5: AMVS_FOR_S(5, step_occupancy_ks, u8)
-    case 7: AMVS_FOR_S(7, step_occupancy_ks, u8)
-    case 9: AMVS_FOR_S(9, step_occupancy_ks, u8)
-    case 11: AMVS_FOR_S(11, step_occupancy_ks, u8)
+    case 3: AMVS_FOR_S(3, step_occupancy_ks, u8, wg_cap)
+    case 5: AMVS_FOR_S(5, step_occupancy_ks, u8, wg_cap)
+    case 7: AMVS_FOR_S(7, step_occupancy_ks, u8, wg_cap)
+    case 9: AMVS_FOR_S(9, step_occupancy_ks, u8, wg_cap)
+    case 11: AMVS_FOR_S(11, step_occupancy_ks, u8, wg_cap)
     default: return 8;
     }
 }
@@ -1088,6 +1126,16 @@ hipError_t launch_init(const Job *jobs, int n_jobs, long long HW, unsigned long 
     const int bx = (int)((HW + 255) / 256 < 2048 ? (HW + 255) / 256 : 2048);
     hipLaunchKernelGGL(pm_init_kernel, dim3(bx, n_jobs), dim3(256), 0, st, jobs, HW, seed,
                        log_scale, log_min, depth, normal, cost);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve_state(const Job *jobs, int n_jobs, long long HW, float *depth, float *nbuf0, const float *nbuf1,
+                                float *depth_out, float *normal_out, long long out_slot0, hipStream_t st)
+{
+    if ((depth_out == nullptr) != (normal_out == nullptr)) return hipErrorInvalidValue;
+    const int bx = (int)((HW + 255) / 256 < 2048 ? (HW + 255) / 256 : 2048);
+    hipLaunchKernelGGL(resolve_state_kernel, dim3(bx, n_jobs), dim3(256), 0, st, jobs, HW, depth, nbuf0, nbuf1,
+                       depth_out, normal_out, out_slot0);
     return hipGetLastError();
 }
 

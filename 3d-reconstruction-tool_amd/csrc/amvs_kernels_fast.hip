@@ -33,14 +33,12 @@ namespace amvs {
 #ifndef AMVS_FAST_MIN_WAVES_BIAS
 #define AMVS_FAST_MIN_WAVES_BIAS 0
 #endif
-// Resident workgroups per CU of the sweep step, enforced through unused dynamic LDS (160 KiB /
-// (static + extra)).  Fewer resident waves touch fewer source rows at once: measured on MI355X
-// (16 views 1080p, k=7, S=4, ms per launch) 6 workgroups = 24 waves per CU 0.897, 5: 0.822, 4: 0.814,
-// 3: 0.856 -- the launch is bound by the CU's L1 line rate for scattered gathers (2 cycles per distinct
-// 128-byte line, tools/gather_rate.hip), not by latency, so the extra waves only add L2 misses.
-#ifndef AMVS_FAST_MAX_WGS_PER_CU
-#define AMVS_FAST_MAX_WGS_PER_CU 4
-#endif
+// Resident workgroups per CU of the sweep step (StepArgs::wg_cap), enforced through unused dynamic
+// LDS (160 KiB / (static + extra)).  Fewer resident waves touch fewer source rows at once: measured on
+// MI355X (16 views 1080p, k=7, S=4, ms per launch, whole-schedule mean) 6 workgroups = 24 waves per CU
+// 0.897, 5: 0.822, 4: 0.814, 3: 0.856 -- the launch is bound by the CU's L1 line rate for scattered
+// gathers (2 cycles per distinct 128-byte line, tools/gather_rate.hip), not by latency, so the extra
+// waves only add L2 misses.
 
 template <int S> struct FRing {
     static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
@@ -49,8 +47,11 @@ template <int S> struct FRing {
 
 template <int K, int S> struct StepLds {
     static constexpr unsigned STATIC = AMVS_WG_WAVES * ((FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u);
-    static constexpr unsigned SHARE = 160u * 1024u / AMVS_FAST_MAX_WGS_PER_CU;
-    static constexpr unsigned EXTRA = STATIC < SHARE ? SHARE - STATIC : 0u;
+    static unsigned extra(int wg_cap)
+    {
+        const unsigned share = 160u * 1024u / (unsigned)(wg_cap > 0 ? wg_cap : AMVS_DEFAULT_WGS_PER_CU);
+        return STATIC < share ? share - STATIC : 0u;
+    }
 };
 
 // the last K reference codes of a lane's column as packed bytes: the window occupies the TOP K
@@ -294,7 +295,7 @@ constexpr int fast_min_waves(int K, int S)
 // (mvs_patchmatch.py:430-436, :468-473).  `d_raw` is d_in at the pixel (+ offset) when `inb`.
 AMVS_DEV float candidate_depth(const StepArgs &a, int mode, bool inb, float d_raw, uint32_t h0)
 {
-    const float dc = inb ? d_raw : a.depth_min;
+    const float dc = inb ? depth_untag(d_raw, a.depth_mask) : a.depth_min;
     const float delta = (rng_uniform(h0) * 2.0f - 1.0f) * a.depth_range;
     float d = dc + delta;
     d = d < a.depth_min ? a.depth_min : d;
@@ -400,10 +401,9 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const GlobalU16 ref_pairs = (GlobalU16)job->ref_pairs;
     const GlobalFloat2s ref_stats = (GlobalFloat2s)job->ref_stats;
     const float *__restrict__ d_in = a.d_in + job->slot * HW;
-    const float *__restrict__ n_in = a.n_in + job->slot * HW * 3;
     float *__restrict__ d_out = a.d_out + job->slot * HW;
     float *cost_io = a.cost + job->slot * HW;
-    float *n_out = a.n_out + job->slot * HW * 3;
+    float *nbuf0 = a.nbuf[0] + job->slot * HW * 3, *nbuf1 = a.nbuf[1] + job->slot * HW * 3;
     float *__restrict__ aux = a.aux + job->slot * HW;
     const uint32_t *__restrict__ smp = PRE ? (const uint32_t *)a.samples + job->slot * HW * S : nullptr;
 
@@ -484,7 +484,16 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = outl ? yc * W + xc : 0;
-        const float oldd = d_in[pc], oldc = cost_io[pc];
+        const float oldd_tagged = d_in[pc], oldc = cost_io[pc];
+        const float oldd = depth_untag(oldd_tagged, a.depth_mask);
+        const unsigned buf_c = depth_buffer(oldd_tagged);     // where this pixel's current normal lives
+        // propagation: the neighbour the candidate was pulled from (requested with the other state
+        // loads: behind the selection it would expose a memory round trip in every row).  Lanes
+        // without an output pixel have pc = 0: they must not form pc + noff, which lies BEFORE the map
+        // for the negative offsets of odd iterations.
+        const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
+        const int pn = (outl & inb_c) ? pc + noff : 0;
+        const float nb_tagged = mode == MODE_PROP ? d_in[pn] : 0.0f;
         const f32x2_t mv1 = ref_stats[pc];
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
@@ -533,41 +542,45 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
         const bool better = act & (newc < oldc);
         if (better) cost_io[pc] = newc;
         if (mode == MODE_PROP) {
-            const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-            const int pn = inb_c ? pc + noff : 0;
-            const int ps = better ? pn : pc;
-            const float nb_d = d_in[pn];
-            float t0 = n_in[3 * ps], t1 = n_in[3 * ps + 1], t2 = n_in[3 * ps + 2];
-            const bool zero = better & !inb_c;
-            if (act) {
-                d_out[pc] = better ? (inb_c ? nb_d : a.depth_min) : oldd;
-                n_out[3 * pc] = zero ? 0.0f : t0;
-                n_out[3 * pc + 1] = zero ? 0.0f : t1;
-                n_out[3 * pc + 2] = zero ? 0.0f : t2;
+            // out-of-image neighbour: depth_min and a zero normal (F.pad, :431-442).  Only the winners'
+            // normals move (StepArgs::nbuf), queued and moved 64 at a time like the refinement winners'.
+            const float nb_d = depth_untag(nb_tagged, a.depth_mask);
+            if (act) d_out[pc] = better ? depth_tag(inb_c ? nb_d : a.depth_min, buf_c ^ 1u) : oldd_tagged;
+            const unsigned long long won = __ballot(better);
+            if (won != 0ull) {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, pn, inb_c, depth_buffer(nb_tagged));
+                q_tail += __popcll(won);
+                if (q_tail - q_head >= AMVS_WAVE) {
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1);
+                    q_head += AMVS_WAVE;
+                }
             }
         } else {
             float delta = (rng_uniform(h0c) * 2.0f - 1.0f) * a.depth_range;
             float d = oldd + delta;
             d = d < a.depth_min ? a.depth_min : d;
             d = d > a.depth_max ? a.depth_max : d;
-            if (act) d_out[pc] = better ? d : oldd;
+            if (act) d_out[pc] = better ? depth_tag(d, buf_c) : oldd_tagged;
             const unsigned long long won = __ballot(better);
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc, h0c);
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc | (buf_c << 31), h0c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, n_out, a.normal_range);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range);
                     q_head += AMVS_WAVE;
                 }
             }
         }
     }
-    if (mode == MODE_REFINE) {
+    if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            refine_normals(nq, q_head, n, lane, n_out, a.normal_range);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1);
             q_head += n;
         }
     }
@@ -847,7 +860,7 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
         else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1, true>), grid, block, 0, st, a);
         return hipGetLastError();
     }
-    constexpr unsigned XL = StepLds<K, S>::EXTRA;
+    const unsigned XL = StepLds<K, S>::extra(a.wg_cap);
     if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, XL, st, a);
     else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, XL, st, a);
     else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1>), grid, block, XL, st, a);
@@ -862,12 +875,12 @@ static hipError_t launch_sweep_fast_ks(const SweepArgs &a, int nblk, hipStream_t
 }
 
 template <int K, int S>
-static int step_fast_occupancy_ks()
+static int step_fast_occupancy_ks(int wg_cap)
 {
     int n = 0;
     constexpr int TPB = AMVS_WAVE * AMVS_WG_WAVES;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pm_step_fast_kernel<K, S, MODE_REFINE>, TPB,
-                                                                StepLds<K, S>::EXTRA);
+                                                                StepLds<K, S>::extra(wg_cap));
     return e == hipSuccess && n > 0 ? n * AMVS_WG_WAVES : 8;
 }
 
@@ -881,14 +894,14 @@ static int step_fast_occupancy_ks()
     default: return decltype(FN<K, 2>(__VA_ARGS__))(1);             \
     }
 
-int step_fast_waves_per_cu(int K, int S)
+int step_fast_waves_per_cu(int K, int S, int wg_cap)
 {
     switch (K) {
-    case 3: AMVS_FOR_S(3, step_fast_occupancy_ks)
-    case 5: AMVS_FOR_S(5, step_fast_occupancy_ks)
-    case 7: AMVS_FOR_S(7, step_fast_occupancy_ks)
-    case 9: AMVS_FOR_S(9, step_fast_occupancy_ks)
-    case 11: AMVS_FOR_S(11, step_fast_occupancy_ks)
+    case 3: AMVS_FOR_S(3, step_fast_occupancy_ks, wg_cap)
+    case 5: AMVS_FOR_S(5, step_fast_occupancy_ks, wg_cap)
+    case 7: AMVS_FOR_S(7, step_fast_occupancy_ks, wg_cap)
+    case 9: AMVS_FOR_S(9, step_fast_occupancy_ks, wg_cap)
+    case 11: AMVS_FOR_S(11, step_fast_occupancy_ks, wg_cap)
     default: return 8;
     }
 }

@@ -83,6 +83,33 @@ class Engine:
         of the sampling kernel, unused LDS bytes per sampling workgroup; 0 = automatic."""
         self._chk(self._lib.amvs_set_split_tuning(self._h, int(groups), int(sample_rows), int(sample_lds_bytes)))
 
+    def set_step_tuning(self, tile_rows=None, wgs_per_cu=None):
+        """Launch shape of the PatchMatch sweep steps by iteration: lists of (propagation, refinement)
+        pairs, one per iteration (0 = automatic; later iterations repeat the last pair); both None
+        clears the table.  Performance only."""
+        n = max(len(tile_rows or []), len(wgs_per_cu or []))
+        if n == 0:
+            self._chk(self._lib.amvs_set_step_tuning(self._h, 0, None, None))
+            return
+
+        def table(t):
+            t = list(t or [])
+            t = t + [t[-1] if t else (0, 0)] * (n - len(t))
+            return np.ascontiguousarray(np.asarray(t, dtype=np.int32).reshape(n, 2))
+        r, w = table(tile_rows), table(wgs_per_cu)
+        self._chk(self._lib.amvs_set_step_tuning(self._h, n, r.ctypes.data_as(i32p), w.ctypes.data_as(i32p)))
+
+    def set_step_timing(self, enable=True):
+        self._chk(self._lib.amvs_set_step_timing(self._h, int(bool(enable))))
+
+    def step_times(self):
+        """Device time (ms) of every sweep launch of the last PatchMatch call (set_step_timing)."""
+        n = C.c_int(0)
+        self._chk(self._lib.amvs_get_step_times(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._chk(self._lib.amvs_get_step_times(self._h, _p(out), out.size, C.byref(n)))
+        return out[: n.value]
+
     # -- lifecycle ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
@@ -243,9 +270,11 @@ class Engine:
                        (depth_ptr, normal_ptr, cost_ptr, conf_ptr))
 
     # -- stereo post-steps on the device --------------------------------------
-    def stereo_backproject(self, colors_bgr, K_inv64, poses, min_confidence, depth=None, conf=None, fetch=False):
+    def stereo_backproject(self, colors_bgr, K_inv64, poses, min_confidence, depth=None, conf=None, fetch=False,
+                           device_ptrs=None):
         """dense_stereo.py:407-437 for all views at once.  depth / conf None: the resident maps of the
-        last plane_sweep_batch.  Returns (per-view point counts, total); the cloud stays on the device
+        last plane_sweep_batch; device_ptrs=(depth_ptr, conf_ptr): maps in caller device memory, (n, H*W)
+        float32 each.  Returns (per-view point counts, total); the cloud stays on the device
         (fetch=True additionally returns points, colours)."""
         cols = np.ascontiguousarray(colors_bgr, dtype=np.uint8)
         n = cols.shape[0]
@@ -254,7 +283,9 @@ class Engine:
         pp = np.ascontiguousarray(np.stack([np.concatenate([np.asarray(R, np.float64).reshape(9),
                                                             np.asarray(t, np.float64).reshape(3)])
                                             for R, t in poses]))
-        if depth is None:
+        if device_ptrs is not None:
+            dptr, cptr, where = C.c_void_p(device_ptrs[0]), C.c_void_p(device_ptrs[1]), 1
+        elif depth is None:
             dptr, cptr, where = C.c_void_p(0), C.c_void_p(0), 2
         else:
             depth, conf = _f32(depth), _f32(conf)

@@ -40,18 +40,34 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def kernel_source_hash(kernel_key):
+    """sha1 over the git blob hashes of the source files a sweep kernel is built from: stored with
+    every profiles/traffic.json entry (tools/profile_summary.py) so that counters of an older kernel
+    are not replayed against a newer build."""
+    import hashlib
+    csrc = os.path.join(ROOT, "3d-reconstruction-tool_amd", "csrc")
+    main = "amvs_kernels_fast.hip" if "_fast_" in kernel_key else "amvs_kernels.hip"
+    h = hashlib.sha1()
+    for name in (main, "amvs_kernel_common.h", "amvs_device.h", "amvs_kernels.h"):
+        with open(os.path.join(csrc, name), "rb") as f:
+            data = f.read()
+        h.update(hashlib.sha1(b"blob %d\0" % len(data) + data).digest())
+    return h.hexdigest()
+
+
 def profiled_traffic(kernel_key, workload_key):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json, written by tools/profile_summary.py; FETCH_SIZE and WRITE_SIZE in KiB,
     collected in separate passes).  FETCH_SIZE is corrected as MI355X_MICROARCH.md prescribes: it
     tallies every 128-byte L2 fill at 64 bytes, so it is doubled -- calibrated for THIS access pattern
     with tools/gather_rate.hip (one dword per 128 bytes moves as many bytes as one per 64 bytes, and
-    TCC_MISS_sum x 64 B reproduces FETCH_SIZE).  None if no profile of this exact workload is committed."""
+    TCC_MISS_sum x 64 B reproduces FETCH_SIZE).  None if no profile of this exact workload AND of the
+    kernel sources in this tree (kernel_source_hash) is committed."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(kernel_key)
-        if e and e.get("workload") == workload_key:
+        if e and e.get("workload") == workload_key and e.get("source_hash") == kernel_source_hash(kernel_key):
             return int((e["fetch_kib"] * e.get("fetch_correction", 1.0) + e["write_kib"]) * 1024)
     except (OSError, ValueError, KeyError):
         pass
@@ -102,6 +118,19 @@ def cpu_baseline(scene, patch, sources, refs, depth_min, depth_max, iters, sampl
             "sample": f"{len(refs)} of the views at {W}x{H}, {iters} iterations x (2+{samples}) evaluations = "
                       f"{n_hyp/1e6:.1f} Mpx-hyp in {dt:.1f} s (oracle/amvs_oracle.c, {mode} arithmetic, "
                       f"OpenMP on {oracle.num_threads()} threads)"}
+
+
+def baseline_label(args, n_views, W, H, world):
+    """"BASELINE config N: " only when the run IS that configuration of BASELINE.json (view count, image
+    size, 7x7 NCC, 8 iterations x (2 + 8) hypotheses; config 5 additionally the fusion inside the step)."""
+    std = (args.patch, args.iters, args.samples) == (7, 8, 8)
+    if std and (n_views, W, H) == (16, 1920, 1080) and world == 1 and not args.fusion:
+        return "BASELINE config 3: "
+    if std and (n_views, W, H) == (32, 1920, 1080) and not args.fusion:
+        return "BASELINE config 4 (the 32-view scene; BASELINE shards it over 4 GPUs, here over %d): " % world
+    if std and (n_views, W, H) == (64, 3840, 2160) and args.fusion:
+        return "BASELINE config 5 (BASELINE shards it over 8 GPUs, here over %d): " % world
+    return "custom workload (no BASELINE config): "
 
 
 def main():
@@ -214,11 +243,13 @@ def main():
     refs = list(mine)
     srcs = [sources[r] for r in refs]
 
-    # N>1: the rank's views are swept in `nb` batches; the RCCL all-gathers of batch b (three
-    # collectives: depth, normal, confidence -- 20 B/pixel, straight from and into contiguous arrays in
-    # view order) run on their own stream while the next batch / the next step is swept, so K timed
-    # steps expose one batch's exchange once, before the closing barrier
-    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 16) else 1)
+    # N>1: the rank's views are swept in `nb` batches (two, even for a 4-view shard); the RCCL
+    # all-gathers of batch b (three collectives: depth, normal, confidence -- 20 B/pixel, straight from
+    # the sweep's output arrays) run on their own stream while the next batch / the next step is swept,
+    # so K timed steps expose one batch's exchange once, before the closing barrier.  `first_step_ms` in
+    # the output line is ONE step from an idle pipeline with its exchange fully inside: what a single
+    # PatchMatchMVS.reconstruct pays (its last group's gather is exposed).
+    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 2) else 1)
     nb = max(1, min(nb, n_loc))
     bounds = [(b * n_loc) // nb for b in range(nb + 1)]
     comm_stream = torch.cuda.Stream(device=dev)
@@ -235,6 +266,10 @@ def main():
                          np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in ids])
     in_flight = []
     state = {"step": 0, "cloud": None, "fusion_s": 0.0}
+    # event on comm_stream behind the collectives that READ output buffer set k: the sweep that
+    # rewrites that set two steps later waits for it on its own stream (the all-gathers read the maps
+    # in place, and ProcessGroupNCCL's work.wait() orders only the stream it is called on)
+    gathered = [None] * nbuf
 
     def drain(keep_last_step):
         while len(in_flight) > (1 if keep_last_step else 0):
@@ -260,6 +295,8 @@ def main():
         k = state["step"] % nbuf
         state["step"] += 1
         works = []
+        if world > 1 and gathered[k] is not None:
+            stream.wait_event(gathered[k])
         for b in range(nb):
             lo, hi = bounds[b], bounds[b + 1]
             eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[k, lo:hi].data_ptr(),
@@ -282,6 +319,12 @@ def main():
                         else:
                             outs = [full[k][name][r, lo:hi] for r in range(world)]
                             works.append(dist.all_gather(outs, inp, async_op=True))
+                    if backend == "nccl":
+                        for w in works:
+                            w.wait()                     # comm_stream (the current stream) waits, not the host
+                    ev = torch.cuda.Event()
+                    ev.record(comm_stream)
+                    gathered[k] = ev
         eng.sync()
         if world > 1:
             in_flight.append(works)
@@ -315,11 +358,16 @@ def main():
         launches += t["sweep_launches"] * nb
     fence()
     elapsed = time.perf_counter() - t0
+    # one step from an idle pipeline, its exchange (and fusion) inside: the latency of one reconstruct
+    t1 = time.perf_counter()
+    step()
+    fence()
+    first_step = time.perf_counter() - t1
     k_last = (state["step"] - 1) % nbuf
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, first_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, first_step = float(tt[0].item()), float(tt[1].item())
         # every rank must now hold every view's maps, in view order: its own block is checked bit for
         # bit and the neighbour's block must be populated
         fd, fc = full[k_last]["d"], full[k_last]["c"]
@@ -348,16 +396,16 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "first_step_ms": round(first_step * 1e3, 2),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ((f"BASELINE config 5: {n_views}-view {W}x{H} PatchMatch MVS + fusion, {vpg} views per GPU, "
-                                     if args.config5 else
-                                     f"BASELINE config 3: {n_views}-view {W}x{H} PatchMatch MVS, ") if world == 1 else
-                                    (f"BASELINE config {5 if args.config5 else 4}: {n_views}-view {W}x{H} PatchMatch MVS scene, "
-                                     f"{vpg} views per GPU, RCCL all-gather of the maps"
+            "config": {"workload": baseline_label(args, n_views, W, H, world) +
+                                   ((f"{n_views}-view {W}x{H} PatchMatch MVS" + (" + fusion, " if args.fusion else ", ")) if world == 1 else
+                                    (f"{n_views}-view {W}x{H} PatchMatch MVS scene, "
+                                     f"{vpg} views per GPU, {'RCCL' if backend == 'nccl' else backend} all-gather of the maps"
                                      + (", fusion inside the step, " if args.fusion else ", "))) +
                                    f"{args.iters} iters x (2+{args.samples}) hypotheses, {args.patch}x{args.patch} NCC, "
                                    f"{S} sources, {args.mode} arithmetic",

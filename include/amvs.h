@@ -143,6 +143,17 @@ int amvs_set_mode(amvs_ctx *ctx, int mode);
 int amvs_get_mode(const amvs_ctx *ctx);
 /* Plane-sweep launch shape: rows per wave strip (1..32) and planes per wave; 0 = automatic.   */
 int amvs_set_sweep_tuning(amvs_ctx *ctx, int tile_rows, int planes_per_wave);
+/* Launch shape of the PatchMatch sweep steps by iteration (performance only; the maps do not depend
+ * on it -- tests/test_hip_fullsize_parity.py): tile_rows / wgs_per_cu are [n_iterations][2] tables,
+ * column 0 = the two propagation launches of an iteration (mvs_patchmatch.py:415-457), column 1 = its
+ * refinement launches (:459-491); an entry 0 = automatic, iterations beyond the table use its last
+ * row, n_iterations = 0 clears it.  wgs_per_cu caps the resident workgroups (4 waves each) per CU.
+ * amvs_pm_params.tile_rows > 0 overrides the row entries.                                      */
+int amvs_set_step_tuning(amvs_ctx *ctx, int n_iterations, const int32_t *tile_rows, const int32_t *wgs_per_cu);
+/* Per-launch device times of the sweep steps of the LAST PatchMatch call (HIP events on the context
+ * stream, recorded when enabled; view groups concatenated, schedule order within a group).      */
+int amvs_set_step_timing(amvs_ctx *ctx, int enable);
+int amvs_get_step_times(amvs_ctx *ctx, float *ms_out, int capacity, int *n_out);
 /* Split schedule (AMVS_SCHEDULE_SPLIT): number of view groups pipelined against each other (1..8),
  * rows per strip of the sampling kernel, and bytes of unused LDS per sampling workgroup (caps how
  * many of them a CU holds, which leaves room for the window kernel); 0 = automatic.              */

@@ -6,7 +6,10 @@
     config 2   8 x 1280x720 plane sweep, 64 planes, 5x5, 6 neighbours, all 8 views in one launch
 
 Each in both arithmetic modes, compared bit for bit with the matching mode of the CPU oracle on
-the views checked (the oracle needs ~0.5 s per 1080p view for a 1-iteration x 2-sample schedule).
+the views checked (the oracle needs ~0.5 s per 1080p view for a 1-iteration x 2-sample schedule,
+~3 s for the full 8 x (2 + 8) schedule the bench times -- test_config3_full_schedule_bit_exact).
+Configs 4 and 5 as WORKLOADS (32 views sharded + gathered, 64 views of 4K + fusion):
+tests/test_hip_workload_parity.py.
 """
 import numpy as np
 import pytest
@@ -68,6 +71,36 @@ def test_config3_16x1080p_batch_bit_exact(scene_1080, mode):
         _eq(depth[r], od, f"{mode} 1080p view {r} depth")
         _eq(conf[r], oc, f"{mode} 1080p view {r} confidence")
         _eq(normal[r], on, f"{mode} 1080p view {r} normal")
+    assert np.isfinite(depth).all()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_config3_full_schedule_bit_exact(scene_1080, mode):
+    """The schedule bench.py times -- 8 iterations x (2 propagation + 8 refinement) hypotheses,
+    mvs_patchmatch.py:287-308 -- on the bench's launch shape (16 views of 1920x1080 in one launch),
+    two views of the batch against the oracle: the late-iteration regime (perturbation range
+    depth_range / 128, coherent gathers, the lean-reciprocal range check, the LDS normal queue under
+    every win rate from ~50 % down to ~1 %) at full size, not only on the 56x72 golden g17."""
+    import amvs
+    from amvs.engine import make_pm_params
+    sc = scene_1080
+    H, W, n = 1080, 1920, 16
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = [pm._select_source_views(r, ids, sc.poses, k=4) for r in ids]
+    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=mode) as eng:
+        for i in ids:
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "u8-pairs"
+        p = make_pm_params(7, 8, 8, sc.depth_min, sc.depth_max)
+        depth, normal, conf = eng.patchmatch(ids, sources, p, 42)
+        assert eng.last_views_per_launch() == 16
+        assert eng.timing()["sweep_launches"] == 80
+    for r in (3, 12):
+        od, on, oc = _oracle_ctx(sc, r, sources[r], 7, mode).patchmatch(8, 8, sc.depth_min, sc.depth_max, 42, r)
+        _eq(depth[r], od, f"{mode} 1080p full schedule view {r} depth")
+        _eq(conf[r], oc, f"{mode} 1080p full schedule view {r} confidence")
+        _eq(normal[r], on, f"{mode} 1080p full schedule view {r} normal")
     assert np.isfinite(depth).all()
 
 

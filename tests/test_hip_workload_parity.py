@@ -1,0 +1,214 @@
+"""BASELINE configs 4 and 5 as WORKLOADS (not only their kernel shapes), and the strip orders.
+
+    config 4   32 views of 1920x1080, the full 8 x (2 + 8) schedule, swept through
+               PatchMatchMVS._sweep_resident by TWO ranks (gloo, both on cuda:0) in launches of 8 and
+               of 4 views -- the shard shapes of a 4- and an 8-GPU split -- and all-gathered: the
+               gathered maps of every rank equal the single-process maps, two of which are compared
+               bit for bit with the CPU oracle (reference loop: mvs_patchmatch.py:104-123, :287-308)
+    config 5   64 views of 3840x2160 through the drop-in class (device image preparation, sweep in
+               launches of 16 views, 1 x 1 schedule), fusion + filter of all 64 maps on the device equal
+               to the NumPy fusion (mvs_patchmatch.py:536-588) of the downloaded maps, two views vs the
+               oracle
+    strips     band-major == view-major == split schedule, bit for bit
+"""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+C4 = dict(n=32, H=1080, W=1920, iters=8, samples=8, seed=42, scene_seed=1234)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _eq(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{what}: {int((~same).sum())} of {same.size} elements differ " \
+                       f"(first at {np.argwhere(~same)[0]}: {a[~same][0]!r} vs {b[~same][0]!r})"
+
+
+def _digest(t):
+    """sha1 of a device tensor's bytes (one row of a resident map)."""
+    return hashlib.sha1(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def _config4_sweep(views_per_batch, keep_rows=()):
+    """The config-4 scene through PatchMatchMVS._sweep_resident (sharded + gathered when a process
+    group is initialised).  Returns ({view: (sha1 depth, sha1 normal, sha1 confidence)}, {view: maps
+    of the rows asked for}, the prepared scene)."""
+    import torch
+
+    import amvs
+    from amvs.core.mvs_patchmatch import PatchMatchMVS
+    from amvs.synthetic import make_scene
+    c = C4
+    sc = make_scene(c["n"], c["H"], c["W"], seed=c["scene_seed"], device="cuda")
+    sc.grays = [(np.round(g * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0)
+                for g in sc.grays]
+    ids = sorted(sc.poses)
+    pm = PatchMatchMVS(amvs.Camera(K=sc.camera.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7,
+                       num_iterations=c["iters"], num_samples=c["samples"], min_views=3, seed=c["seed"],
+                       views_per_batch=views_per_batch, device=0, mode="fast", device_prep=False)
+    pm.depth_min, pm.depth_max = sc.depth_min, sc.depth_max
+    proc = {i: {"gray": sc.grays[i], "color": sc.colors[i], "shape": (c["H"], c["W"])} for i in ids}
+    jobs = [(r, pm._select_source_views(r, ids, sc.poses, k=4)) for r in ids]
+    res = pm._sweep_resident(torch, jobs, proc, sc.poses, ids)
+    torch.cuda.synchronize()
+    assert res.ref_ids == ids
+    digests = {r: (_digest(res.depth[i]), _digest(res.normal[i]), _digest(res.confidence[i]))
+               for i, r in enumerate(res.ref_ids)}
+    H, W = c["H"], c["W"]
+    kept = {r: (res.depth[r].cpu().numpy().reshape(H, W), res.normal[r].cpu().numpy().reshape(H, W, 3),
+                res.confidence[r].cpu().numpy().reshape(H, W)) for r in keep_rows}
+    pm._engine.close()
+    return digests, kept, (sc, jobs)
+
+
+def _config4_worker(rank, world, port, q, views_per_batch):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        digests, _, _ = _config4_sweep(views_per_batch)
+        q.put((rank, digests))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope="module")
+def config4_single():
+    return _config4_sweep(16, keep_rows=(5, 26))
+
+
+@pytest.mark.timeout(900)
+def test_config4_single_process_views_match_the_oracle(config4_single):
+    from oracle import oracle
+    oracle.set_threads(16)
+    _, kept, (sc, jobs) = config4_single
+    c = C4
+    for r, (d, n, cf) in kept.items():
+        srcs = jobs[r][1]
+        ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), sc.grays[r], sc.poses[r].R, sc.poses[r].t,
+                                 [sc.grays[i] for i in srcs], [sc.poses[i].R for i in srcs],
+                                 [sc.poses[i].t for i in srcs], 7, mode="fast")
+        od, on, oc = ctx.patchmatch(c["iters"], c["samples"], sc.depth_min, sc.depth_max, c["seed"], r)
+        _eq(d, od, f"config 4 view {r} depth")
+        _eq(cf, oc, f"config 4 view {r} confidence")
+        _eq(n, on, f"config 4 view {r} normal")
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("views_per_batch", [8, 4])
+def test_config4_two_ranks_rank_shaped_shards_gathered(config4_single, views_per_batch):
+    """Two gloo ranks on cuda:0, 16 views each, swept in launches of 8 (the 4-GPU shard) or 4 views (the
+    8-GPU shard) and all-gathered: every rank ends with the single-process maps of all 32 views."""
+    import torch.multiprocessing as mp
+    single, _, _ = config4_single
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, 2, port, q, views_per_batch)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, digests in results:
+        assert sorted(digests) == sorted(single)
+        bad = [r for r in single if digests[r] != single[r]]
+        assert not bad, f"rank {rank}, {views_per_batch} views per launch: gathered maps of views {bad} differ"
+
+
+@pytest.mark.timeout(1200)
+def test_config5_64x4k_workload_fusion_on_device():
+    """BASELINE config 5 on one GPU: 64 views of 3840x2160 through the class's own pipeline -- 8-bit BGR
+    uploads prepared on the device, sweep in launches of 16 views, maps resident, fusion + filter of
+    all 64 maps on the device -- against the NumPy fusion of the downloaded maps and, for two views,
+    the oracle."""
+    import torch
+
+    import amvs
+    from amvs.core.imageprep import prepare_view
+    from amvs.core.mvs_patchmatch import PatchMatchMVS
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    n, H, W = 64, 2160, 3840
+    sc = make_scene(n, H, W, seed=4, device="cuda")
+    sc.grays = sc.depths = None                                    # (2 x 2.1 GB of host arrays nobody reads here)
+    ids = sorted(sc.poses)
+    pm = PatchMatchMVS(amvs.Camera(K=sc.camera.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7,
+                       num_iterations=1, num_samples=1, min_views=3, seed=7, views_per_batch=16, device=0,
+                       mode="fast", device_prep=True)
+    pm.depth_min, pm.depth_max = sc.depth_min, sc.depth_max
+    proc = pm._prepare_images_device(sc.images(), ids, sc.poses)
+    jobs = [(r, pm._select_source_views(r, ids, sc.poses, k=4)) for r in ids]
+    res = pm._sweep_resident(torch, jobs, proc, sc.poses, ids)
+    assert pm._engine.last_views_per_launch() == 16
+    pts, cols, raw = pm._fuse_filter_resident(res, proc, sc.poses)
+    assert raw > 1000 and len(pts) > 1000, (raw, len(pts))
+    host = res.to_host()
+    hp, hc = pm._fuse_depth_maps(host, proc, sc.poses)
+    assert len(hp) == raw
+    hp, hc = pm._filter_points(hp, hc)
+    assert np.array_equal(pts, hp), "device fusion + filter of the 64 maps differs from the NumPy fusion"
+    assert np.array_equal(cols, hc)
+    oracle.set_threads(16)
+    for r in (9, 40):
+        srcs = jobs[r][1]
+        g = {i: prepare_view(sc.colors[i], 1.0)["gray"] for i in [r] + srcs}
+        ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), g[r], sc.poses[r].R, sc.poses[r].t,
+                                 [g[i] for i in srcs], [sc.poses[i].R for i in srcs],
+                                 [sc.poses[i].t for i in srcs], 7, mode="fast")
+        od, on, oc = ctx.patchmatch(1, 1, sc.depth_min, sc.depth_max, 7, r)
+        _eq(host[r].depth, od, f"config 5 view {r} depth")
+        _eq(host[r].confidence, oc, f"config 5 view {r} confidence")
+        _eq(host[r].normal, on, f"config 5 view {r} normal")
+    pm._engine.close()
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_strip_orders_give_identical_maps(mode):
+    """amvs_pm_params.schedule: band-major strips (every XCD walks one band of ALL views, strip height
+    from pick_band_rows) and -- fast arithmetic -- the split schedule (sampling kernel + window kernel
+    on two streams) return the view-major maps bit for bit; 6 views of 540x960, 2 x (2 + 3) steps, so
+    that bands of several views share an XCD and strips end inside the image."""
+    import torch
+
+    import amvs
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    n, H, W = 6, 540, 960
+    sc = make_scene(n, H, W, seed=21, device="cuda" if torch.cuda.is_available() else "cpu")
+    grays = [(np.round(g * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0)
+             for g in sc.grays]
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = [pm._select_source_views(r, ids, sc.poses, k=4) for r in ids]
+    maps, rows = {}, {}
+    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=mode) as eng:
+        for i in ids:
+            eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+        for schedule in ["view-major", "band-major"] + (["split"] if mode == "fast" else []):
+            p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule=schedule)
+            maps[schedule] = eng.patchmatch(ids, sources, p, 11)
+            rows[schedule] = eng.last_tile_rows()
+    assert rows["band-major"] != rows["view-major"], rows          # a different launch shape was really used
+    for schedule in maps:
+        for a, b, what in zip(maps["view-major"], maps[schedule], ("depth", "normal", "confidence")):
+            _eq(b, a, f"{mode} {schedule} {what}")

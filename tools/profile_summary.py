@@ -73,6 +73,11 @@ print("\n".join(out))
 if workload_key and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     path = "profiles/traffic.json"
     t = json.load(open(path)) if os.path.exists(path) else {}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash            # the counters belong to THESE kernel sources
     t[kernel_key] = {"workload": workload_key, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"],
-                     "fetch_correction": 2.0, "source": tag}
+                     "fetch_correction": 2.0, "source": tag, "source_hash": kernel_source_hash(kernel_key)}
+    for extra in ("TCC_HIT_sum", "TCC_MISS_sum"):
+        if extra in vals:
+            t[kernel_key][extra.lower()] = vals[extra]
     json.dump(t, open(path, "w"), indent=1)
