@@ -115,7 +115,12 @@ int amvs_set_view_device(amvs_ctx *ctx, int view, const void *gray_device,
  * built from it directly.  scaled_bgr_out (optional, H x W x 3) receives the resized colour image the
  * fusion takes its colours from.  The context must have been created with H = int(src_h * scale),
  * W = int(src_w * scale).  OpenCV is absent from the build container: the arithmetic restates its
- * published source and equals core/imageprep.py bit for bit; parity with cv2 itself is unpinned.   */
+ * published source and equals core/imageprep.py bit for bit; parity with cv2 itself is unpinned.
+ * STATED TOLERANCE against cv2 (a5): bit equality of the resized colour image and of the gray codes is
+ * expected for OpenCV 4.x's generic code path; an OpenCV build that dispatches the 8-bit resize to IPP
+ * or another HAL, or OpenCV 3.x's 14-bit gray coefficients, may differ by at most +-1 gray code (1/255)
+ * on isolated pixels.  tests/test_host_logic.py::test_image_preparation_equals_cv2_when_present checks
+ * the bit equality wherever cv2 is importable; the Python classes use cv2 itself there by default.   */
 int amvs_set_view_bgr8(amvs_ctx *ctx, int view, const uint8_t *bgr_host, int src_h, int src_w,
                        const float R[9], const float t[3], uint8_t *scaled_bgr_out);
 

@@ -187,6 +187,38 @@ def test_prepare_view_identity_scale_and_gray_formula():
                for p, q in zip(pooled, serial))
 
 
+def test_save_ply_matches_the_reference_golden(tmp_path):
+    """amvs_write_ply against the bytes the reference's own utils.save_ply (utils.py:8-37) wrote for the
+    same cloud (g18_ply, captured by tests/golden/make_golden_r3.py): header, `%.6f` rounding incl.
+    negative zero, denormals and round-up at the sixth decimal, the empty cloud."""
+    from conftest import load_golden
+    from amvs.core.utils import save_ply
+    g = load_golden("g18_ply")
+    out = tmp_path / "sub" / "cloud.ply"
+    save_ply(g["points"], g["colors"], str(out))
+    assert out.read_bytes() == g["ply_bytes"].tobytes()
+    save_ply(np.zeros((0, 3)), np.zeros((0, 3), np.uint8), str(tmp_path / "empty.ply"))
+    assert (tmp_path / "empty.ply").read_bytes() == g["ply_bytes_empty"].tobytes()
+
+
+def test_image_preparation_equals_cv2_when_present():
+    """wherever OpenCV is importable, the restated 8-bit resize / BGR2GRAY (core/imageprep.py,
+    and with it the bit-identical device path amvs_set_view_bgr8) must equal cv2 itself for several
+    scales, incl. the 0.5 / 0.25 reductions the CLI uses.  Skipped in the build container (no cv2: image
+    preparation stays parity-UNPINNED there)."""
+    cv2 = pytest.importorskip("cv2")
+    from amvs.core import imageprep
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    for scale in (1.0, 0.75, 0.5, 0.37, 0.25):
+        h, w = int(96 * scale), int(128 * scale)
+        want_c = cv2.resize(img, (w, h))
+        want_g = cv2.cvtColor(want_c, cv2.COLOR_BGR2GRAY)
+        got_c = imageprep._resize_linear_u8(img, w, h)
+        assert np.array_equal(got_c, want_c), f"resize differs from cv2 at scale {scale}"
+        assert np.array_equal(imageprep._bgr_to_gray_u8(got_c), want_g), f"gray differs from cv2 at scale {scale}"
+
+
 def test_save_ply_writes_the_reference_bytes(tmp_path):
     """The native writer against a straight restatement of utils.save_ply (utils.py:20-35)."""
     from amvs.core.utils import save_ply
