@@ -83,7 +83,10 @@ SIGNATURES = {
     "amvs_xpm_init": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_uint64,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_xpm_iterate": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_int, C.c_uint64,
-                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amvs_xpm_step": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_int, C.c_uint64, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "amvs_xpm_fetch_candidates": (C.c_int, [C.c_void_p, C.c_int, f32p, f32p]),
     "amvs_xpm_consistency": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams),
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "amvs_eval_cost": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f32p, f32p]),

@@ -530,8 +530,16 @@ class PatchMatchMVS:
         eng.sync()
         exchange()
         for it in range(self.num_iterations):
+            # several calls per iteration (jobs with different source counts): their view candidates
+            # read a copy of the maps taken before the first call writes, so that the result does not
+            # depend on the grouping (nor on the rank layout)
+            snap = (depth.clone(), normal.clone()) if len(calls) > 1 else None
+            if snap is not None:
+                torch.cuda.synchronize(dev)
             for refs, srcs, _ in calls:
-                eng.xpm_iterate(refs, srcs, params, it, self.seed_for_stream(), *ptrs)
+                eng.xpm_iterate(refs, srcs, params, it, self.seed_for_stream(), *ptrs,
+                                snapshot_depth_ptr=snap[0].data_ptr() if snap else 0,
+                                snapshot_normal_ptr=snap[1].data_ptr() if snap else 0)
             eng.sync()
             exchange()
         conf = torch.zeros((len(jobs), hw), dtype=torch.float32, device=dev)

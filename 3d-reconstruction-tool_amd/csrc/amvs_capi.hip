@@ -1393,6 +1393,7 @@ static int xpm_begin(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_
     a.jobs = c->d_jobs; a.images = c->d_images; a.img_stride = c->stride;
     a.pairs = usable_pairs(c); a.pair_stride = c->pstride;
     a.depth = (float *)depth_all; a.normal = (float *)normal_all; a.cost = (float *)cost_all;
+    a.snap_depth = a.depth; a.snap_normal = a.normal;
     a.cand_d = c->d_xcand_d; a.cand_n = c->d_xcand_n; a.src_view = c->d_xsrc;
     a.patch = p->patch_size; a.stride = p->window_stride;
     a.depth_min = p->depth_min; a.depth_max = p->depth_max;
@@ -1410,31 +1411,83 @@ int amvs_xpm_init(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids
     return AMVS_OK;
 }
 
-int amvs_xpm_iterate(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
-                     int iteration, uint64_t seed, void *depth_all, void *normal_all, void *cost_all)
+// ranges / hypothesis set of one iteration (shared by amvs_xpm_iterate and amvs_xpm_step)
+static void xpm_iteration_args(amvs::XArgs &a, const amvs_xpm_params *p, int iteration, uint64_t seed)
 {
-    amvs::XArgs a;
-    int rc = xpm_begin(c, n_ref, ref_ids, src_ids, n_src, p, depth_all, normal_all, cost_all, a);
-    if (rc) return rc;
-    if (iteration < 0) return fail(c, AMVS_EINVAL, "negative iteration");
     a.seed = seed;
     const double shrink = std::pow(0.5, iteration);
     a.rel_range = (float)std::max(0.2 * shrink, 0.004);
     a.nrm_range = (float)std::max(0.4 * shrink, 0.01);
     a.n_refine = p->num_refine < 0 ? 0 : (p->num_refine > 6 ? 6 : p->num_refine);
     a.with_random = iteration < 2;
-    // view propagation from a snapshot: the candidates of this iteration come from source
-    // (iteration mod n_src) of every view, read before any map is written
     a.with_view_cand = p->view_propagation ? 1 : 0;
-    if (a.with_view_cand) {
-        a.colour = iteration % n_src;
-        HIPCHK(c, amvs::launch_xpm_view_candidates(a, c->stream));
-    }
-    for (int colour = 0; colour < 2; ++colour) {
-        a.colour = colour;
-        a.draw = (unsigned)(1 + 2 * iteration + colour);
+}
+
+static int xpm_run_phase(amvs_ctx *c, amvs::XArgs a, int n_src, int iteration, int phase, void *cost_out)
+{
+    if (phase == AMVS_XPM_PHASE_CANDIDATES) {
+        // view propagation from a snapshot: the candidates of this iteration come from source
+        // (iteration mod n_src) of every view, read from maps no call of this iteration has written
+        if (a.with_view_cand) {
+            a.colour = iteration % n_src;
+            HIPCHK(c, amvs::launch_xpm_view_candidates(a, c->stream));
+        }
+    } else if (phase == AMVS_XPM_PHASE_RED || phase == AMVS_XPM_PHASE_BLACK) {
+        a.colour = phase - AMVS_XPM_PHASE_RED;
+        a.draw = (unsigned)(1 + 2 * iteration + a.colour);
         HIPCHK(c, amvs::launch_xpm_sweep(a, c->stream));
+    } else {
+        if (!cost_out) return fail(c, AMVS_EINVAL, "NULL output");
+        HIPCHK(c, amvs::launch_xpm_eval(a, (float *)cost_out, c->stream));
     }
+    return AMVS_OK;
+}
+
+static int xpm_phases(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                      int iteration, uint64_t seed, int first_phase, int last_phase, void *depth_all, void *normal_all,
+                      void *cost_all, const void *snapshot_depth, const void *snapshot_normal, void *cost_out)
+{
+    amvs::XArgs a;
+    int rc = xpm_begin(c, n_ref, ref_ids, src_ids, n_src, p, depth_all, normal_all, cost_all, a);
+    if (rc) return rc;
+    if (iteration < 0) return fail(c, AMVS_EINVAL, "negative iteration");
+    if ((snapshot_depth == nullptr) != (snapshot_normal == nullptr)) return fail(c, AMVS_EINVAL, "snapshot: both maps or none");
+    if (snapshot_depth) { a.snap_depth = (const float *)snapshot_depth; a.snap_normal = (const float *)snapshot_normal; }
+    xpm_iteration_args(a, p, iteration, seed);
+    for (int phase = first_phase; phase <= last_phase; ++phase)
+        if ((rc = xpm_run_phase(c, a, n_src, iteration, phase, cost_out))) return rc;
+    return AMVS_OK;
+}
+
+int amvs_xpm_step(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                  int iteration, uint64_t seed, int phase, void *depth_all, void *normal_all, void *cost_all,
+                  const void *snapshot_depth, const void *snapshot_normal, void *cost_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (phase < AMVS_XPM_PHASE_CANDIDATES || phase > AMVS_XPM_PHASE_EVAL) return fail(c, AMVS_EINVAL, "unknown phase");
+    return xpm_phases(c, n_ref, ref_ids, src_ids, n_src, p, iteration, seed, phase, phase, depth_all, normal_all, cost_all,
+                      snapshot_depth, snapshot_normal, cost_out);
+}
+
+int amvs_xpm_iterate(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_ids, int n_src, const amvs_xpm_params *p,
+                     int iteration, uint64_t seed, void *depth_all, void *normal_all, void *cost_all,
+                     const void *snapshot_depth, const void *snapshot_normal)
+{
+    if (!c) return AMVS_EINVAL;
+    return xpm_phases(c, n_ref, ref_ids, src_ids, n_src, p, iteration, seed, AMVS_XPM_PHASE_CANDIDATES, AMVS_XPM_PHASE_BLACK,
+                      depth_all, normal_all, cost_all, snapshot_depth, snapshot_normal, nullptr);
+}
+
+int amvs_xpm_fetch_candidates(amvs_ctx *c, int n_ref, float *cand_depth_out, float *cand_normal_out)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!cand_depth_out || !cand_normal_out || n_ref < 1 || n_ref > c->cap_x) return fail(c, AMVS_EINVAL, "bad argument / no candidates");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const size_t hw = (size_t)c->H * c->W;
+    HIPCHK(c, hipMemcpyAsync(cand_depth_out, c->d_xcand_d, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(cand_normal_out, c->d_xcand_n, 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return AMVS_OK;
 }
 

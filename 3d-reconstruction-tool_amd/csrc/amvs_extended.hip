@@ -294,13 +294,13 @@ __global__ __launch_bounds__(256) void xpm_view_candidates_kernel(const XArgs a)
     const long long HW = (long long)H * W;
     const long long rbase = (long long)job->ref_img * HW, cbase = (long long)job->slot * HW;
     const int sv = a.src_view[job->slot * a.n_src + s];
-    const float *sd = a.depth + (long long)sv * HW, *sn = a.normal + 3ll * sv * HW;
+    const float *sd = a.snap_depth + (long long)sv * HW, *sn = a.snap_normal + 3ll * sv * HW;
     const CF M = job->fsrc[s].M, b = job->fsrc[s].b;
     const CF Rr = job->Rref, tr = job->tref, Rs = job->src[s].R, ts = job->src[s].t, Ki = job->Kinv;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(i / W), x = (int)(i - (long long)y * W);
         float cd = 0.0f, cnx = 0.f, cny = 0.f, cnz = -1.f;          // depth 0 = no candidate
-        const float d = a.depth[rbase + i];
+        const float d = a.snap_depth[rbase + i];
         const float fx = (float)x, fy = (float)y;
         const float q0 = __builtin_fmaf(M[1], fy, __builtin_fmaf(M[0], fx, M[2]));
         const float q1 = __builtin_fmaf(M[4], fy, __builtin_fmaf(M[3], fx, M[5]));
@@ -425,6 +425,31 @@ __global__ __launch_bounds__(128) void xpm_sweep_kernel(const XArgs a)
     }
 }
 
+// test hook (amvs_xpm_step, phase 3): the cost of every pixel's current plane, no selection
+template <int NT, bool U8>
+__global__ __launch_bounds__(128) void xpm_eval_kernel(const XArgs a, float *__restrict__ cost_out)
+{
+    const JobCP job = (JobCP)(a.jobs + blockIdx.y);
+    const int H = a.H, W = a.W;
+    const long long HW = (long long)H * W;
+    const long long rbase = (long long)job->ref_img * HW, cbase = (long long)job->slot * HW;
+    const float *ref = a.images + (long long)job->ref_img * a.img_stride;
+    const CF Ki = job->Kinv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (long long)y * W);
+        const float d = a.depth[rbase + i];
+        const float nx = a.normal[3 * (rbase + i)], ny = a.normal[3 * (rbase + i) + 1], nz = a.normal[3 * (rbase + i) + 2];
+        const float rpx = __builtin_fmaf(Ki[1], (float)y, __builtin_fmaf(Ki[0], (float)x, Ki[2]));
+        const float rpy = __builtin_fmaf(Ki[4], (float)y, __builtin_fmaf(Ki[3], (float)x, Ki[5]));
+        constexpr int NR = NT > 0 ? NT : 1;
+        const XRef<NR> R = NT > 0 ? xref_load<NR>(a, ref, x, y) : XRef<NR>{};
+        float c;
+        if constexpr (NT > 0) c = xcost_t<NT, U8>(a, job, R, x, y, rpx, rpy, d, nx, ny, nz);
+        else c = xcost(a, job, ref, x, y, d, nx, ny, nz);
+        cost_out[cbase + i] = c;
+    }
+}
+
 // geometric consistency: sources whose own map agrees after forward-backward reprojection
 __global__ __launch_bounds__(256) void xpm_consistency_kernel(const XArgs a, float *__restrict__ conf_out, float max_px,
                                                               float max_rel)
@@ -506,6 +531,27 @@ hipError_t launch_xpm_sweep(const XArgs &a, hipStream_t st)
     default: hipLaunchKernelGGL((xpm_sweep_kernel<0, false>), grid, blk, 0, st, a); break;
     }
 #undef AMVS_XSWEEP
+    return hipGetLastError();
+}
+
+hipError_t launch_xpm_eval(const XArgs &a, float *cost_out, hipStream_t st)
+{
+    const dim3 grid = xgrid((long long)a.H * a.W, 128, a.n_jobs), blk(128);
+    const int n = (a.patch - 1) / a.stride + 1;
+    const bool fits = (n - 1) * a.stride + 1 == a.patch;
+    const bool u8 = a.pairs != nullptr;
+#define AMVS_XEVAL(NT_)                                                                                       \
+    if (u8) hipLaunchKernelGGL((xpm_eval_kernel<NT_, true>), grid, blk, 0, st, a, cost_out);                     \
+    else hipLaunchKernelGGL((xpm_eval_kernel<NT_, false>), grid, blk, 0, st, a, cost_out)
+    switch (fits ? n : 0) {
+    case 3: AMVS_XEVAL(3); break;
+    case 4: AMVS_XEVAL(4); break;
+    case 5: AMVS_XEVAL(5); break;
+    case 6: AMVS_XEVAL(6); break;
+    case 7: AMVS_XEVAL(7); break;
+    default: hipLaunchKernelGGL((xpm_eval_kernel<0, false>), grid, blk, 0, st, a, cost_out); break;
+    }
+#undef AMVS_XEVAL
     return hipGetLastError();
 }
 

@@ -168,6 +168,8 @@ struct XArgs {
     const uint16_t *pairs;        // packed 8-bit row-pair maps [n_views][pair_stride] (NULL: sample `images`)
     long long pair_stride;
     float *depth, *normal, *cost; // state of ALL views: [n_views][H*W] (normal x3), indexed by Job::ref_img
+    const float *snap_depth, *snap_normal;   // what the view candidates read: a snapshot of depth / normal taken
+                                             // before any call of the iteration wrote a map (or the live maps)
     float *cand_d, *cand_n;       // view-propagation candidates [n_jobs][H*W] (x3), indexed by Job::slot
     const int *src_view;          // [n_jobs][n_src] view ids of the sources
     int patch, stride;            // window side, sample stride inside it
@@ -181,6 +183,7 @@ struct XArgs {
 hipError_t launch_xpm_init(const XArgs &a, float log_scale, float log_min, hipStream_t st);
 hipError_t launch_xpm_view_candidates(const XArgs &a, hipStream_t st);
 hipError_t launch_xpm_sweep(const XArgs &a, hipStream_t st);
+hipError_t launch_xpm_eval(const XArgs &a, float *cost_out, hipStream_t st);   // test hook: cost of every pixel's current plane
 hipError_t launch_xpm_consistency(const XArgs &a, float *conf_out, float max_px, float max_rel, hipStream_t st);
 
 // amvs_prep.hip: cv.resize (INTER_LINEAR, 8-bit BGR) + cvtColor(BGR2GRAY) / 255 of one view; the

@@ -261,9 +261,34 @@ class Engine:
     def xpm_init(self, ref_ids, src_ids, params, seed, depth_ptr, normal_ptr, cost_ptr):
         self._xpm_call(self._lib.amvs_xpm_init, ref_ids, src_ids, params, (int(seed),), (depth_ptr, normal_ptr, cost_ptr))
 
-    def xpm_iterate(self, ref_ids, src_ids, params, iteration, seed, depth_ptr, normal_ptr, cost_ptr):
+    def xpm_iterate(self, ref_ids, src_ids, params, iteration, seed, depth_ptr, normal_ptr, cost_ptr,
+                    snapshot_depth_ptr=0, snapshot_normal_ptr=0):
+        """One iteration (view candidates, red and black half sweeps).  snapshot_*: device copies of the
+        depth / normal maps the view candidates read (0 = the live maps); pass them when the views of one
+        iteration are split over several calls."""
         self._xpm_call(self._lib.amvs_xpm_iterate, ref_ids, src_ids, params, (int(iteration), int(seed)),
-                       (depth_ptr, normal_ptr, cost_ptr))
+                       (depth_ptr, normal_ptr, cost_ptr, snapshot_depth_ptr or None, snapshot_normal_ptr or None))
+
+    XPM_PHASES = {"candidates": 0, "red": 1, "black": 2, "eval": 3}
+
+    def xpm_step(self, ref_ids, src_ids, params, iteration, seed, phase, depth_ptr, normal_ptr, cost_ptr,
+                 snapshot_depth_ptr=0, snapshot_normal_ptr=0, cost_out_ptr=0):
+        """One phase of an iteration ("candidates", "red", "black") or the test hook "eval" (cost of the
+        current planes into cost_out_ptr)."""
+        ref, refp = _ids(ref_ids)
+        src, srcp = _ids(src_ids)
+        n = ref.shape[0]
+        src = src.reshape(n, -1)
+        self._chk(self._lib.amvs_xpm_step(self._h, n, refp, srcp, src.shape[1], C.byref(params), int(iteration), int(seed),
+                                          self.XPM_PHASES[phase], C.c_void_p(depth_ptr), C.c_void_p(normal_ptr),
+                                          C.c_void_p(cost_ptr), C.c_void_p(snapshot_depth_ptr or None),
+                                          C.c_void_p(snapshot_normal_ptr or None), C.c_void_p(cost_out_ptr or None)))
+
+    def xpm_fetch_candidates(self, n_ref):
+        d = np.empty((n_ref, self.H, self.W), np.float32)
+        n = np.empty((n_ref, self.H, self.W, 3), np.float32)
+        self._chk(self._lib.amvs_xpm_fetch_candidates(self._h, int(n_ref), _p(d), _p(n)))
+        return d, n
 
     def xpm_consistency(self, ref_ids, src_ids, params, depth_ptr, normal_ptr, cost_ptr, conf_ptr):
         self._xpm_call(self._lib.amvs_xpm_consistency, ref_ids, src_ids, params, (),

@@ -263,9 +263,29 @@ typedef struct {
 } amvs_xpm_params;
 int amvs_xpm_init(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
                   const amvs_xpm_params *p, uint64_t seed, void *depth_all, void *normal_all, void *cost_all);
+/* One iteration = view candidates, red half sweep, black half sweep.  snapshot_depth / snapshot_normal
+ * (device, same layout as depth_all / normal_all; NULL = the live maps): what the view candidates
+ * read.  A caller that splits the views of one iteration over several calls (jobs with different
+ * source counts) passes a copy taken before the first call, so that no call sees maps another call
+ * of the same iteration already wrote -- the result then does not depend on the grouping.          */
 int amvs_xpm_iterate(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
                      const amvs_xpm_params *p, int iteration, uint64_t seed,
-                     void *depth_all, void *normal_all, void *cost_all);
+                     void *depth_all, void *normal_all, void *cost_all,
+                     const void *snapshot_depth, const void *snapshot_normal);
+/* The phases of an iteration one at a time (tests/test_extended_oracle.py compares each with the CPU
+ * restatement oracle/xpm_oracle.py), plus a test hook: AMVS_XPM_PHASE_EVAL writes the cost of every
+ * pixel's CURRENT plane to cost_out ([n_ref][H][W], device) and changes nothing.                     */
+#define AMVS_XPM_PHASE_CANDIDATES 0
+#define AMVS_XPM_PHASE_RED        1
+#define AMVS_XPM_PHASE_BLACK      2
+#define AMVS_XPM_PHASE_EVAL       3
+int amvs_xpm_step(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
+                  const amvs_xpm_params *p, int iteration, uint64_t seed, int phase,
+                  void *depth_all, void *normal_all, void *cost_all,
+                  const void *snapshot_depth, const void *snapshot_normal, void *cost_out);
+/* The view-propagation candidates of the last AMVS_XPM_PHASE_CANDIDATES call: depth [n_ref][H][W]
+ * (0 = none), normal [n_ref][H][W][3], host arrays (test hook).                                       */
+int amvs_xpm_fetch_candidates(amvs_ctx *ctx, int n_ref, float *cand_depth_out, float *cand_normal_out);
 int amvs_xpm_consistency(amvs_ctx *ctx, int n_ref, const int *ref_ids, const int *src_ids, int n_src,
                          const amvs_xpm_params *p, void *depth_all, void *normal_all, void *cost_all,
                          void *conf_out);

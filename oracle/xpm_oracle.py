@@ -1,0 +1,321 @@
+"""CPU restatement (NumPy, float32) of the EXTENDED PatchMatch mode's kernels
+(3d-reconstruction-tool_amd/csrc/amvs_extended.hip): the slanted-plane window cost `xcost_t`, the
+view-propagation candidates and one red-black half sweep.
+
+TEST INFRASTRUCTURE ONLY (imported by tests/test_extended_oracle.py).  The extended mode has NO
+reference counterpart -- the reference's docstring names plane normals and view propagation
+(mvs_patchmatch.py:1-13), its code implements neither (:323-390, :415-457) -- so this file is not pinned
+against reference outputs: it is an independent second implementation of the same specification,
+written from the kernel's documented arithmetic, against which the HIP kernels are compared with a
+STATED TOLERANCE (the kernels use v_rcp_f32 / v_rsq_f32, exp / log of the device library and real
+FMAs; this file uses IEEE division / sqrt, NumPy's exp / log and FMAs emulated in float64).
+
+Conventions: images are 8-bit codes (H, W) uint8; gray = code / 255 in float32; state maps depth
+(H, W), normal (H, W, 3), cost (H, W) float32; K, K_inv float32 3x3 (K_inv as the engine forms it:
+the float32 inverse); poses (R, t) world -> camera.
+"""
+import numpy as np
+
+F = np.float32
+INF = F(np.inf)
+
+
+def fma(a, b, c):
+    """fmaf emulated through float64 (the product of two float32 is exact in float64)."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def compose(K, Rr, tr, Rs, ts):
+    """fast_compose (csrc/amvs_kernels_fast.hip): M = K R_s R_ref^T K^-1, b = K (t_s - R_s R_ref^T t_ref) in
+    double on the float32 operands, sums left to right, K^-1 by cofactors, one rounding at the end."""
+    Kd = np.asarray(K, np.float32).astype(np.float64).reshape(9)
+    Rr = np.asarray(Rr, np.float32).astype(np.float64).reshape(9)
+    Rs = np.asarray(Rs, np.float32).astype(np.float64).reshape(9)
+    tr = np.asarray(tr, np.float32).astype(np.float64).reshape(3)
+    ts = np.asarray(ts, np.float32).astype(np.float64).reshape(3)
+    det = Kd[0] * (Kd[4] * Kd[8] - Kd[5] * Kd[7]) - Kd[1] * (Kd[3] * Kd[8] - Kd[5] * Kd[6]) + Kd[2] * (Kd[3] * Kd[7] - Kd[4] * Kd[6])
+    Ki = np.array([(Kd[4] * Kd[8] - Kd[5] * Kd[7]) / det, (Kd[2] * Kd[7] - Kd[1] * Kd[8]) / det, (Kd[1] * Kd[5] - Kd[2] * Kd[4]) / det,
+                   (Kd[5] * Kd[6] - Kd[3] * Kd[8]) / det, (Kd[0] * Kd[8] - Kd[2] * Kd[6]) / det, (Kd[2] * Kd[3] - Kd[0] * Kd[5]) / det,
+                   (Kd[3] * Kd[7] - Kd[4] * Kd[6]) / det, (Kd[1] * Kd[6] - Kd[0] * Kd[7]) / det, (Kd[0] * Kd[4] - Kd[1] * Kd[3]) / det])
+    Rrel = np.empty(9)
+    for i in range(3):
+        for j in range(3):
+            Rrel[3 * i + j] = (Rs[3 * i] * Rr[3 * j] + Rs[3 * i + 1] * Rr[3 * j + 1]) + Rs[3 * i + 2] * Rr[3 * j + 2]
+    trel = np.array([ts[i] - ((Rrel[3 * i] * tr[0] + Rrel[3 * i + 1] * tr[1]) + Rrel[3 * i + 2] * tr[2]) for i in range(3)])
+    A = np.empty(9)
+    for i in range(3):
+        for j in range(3):
+            A[3 * i + j] = (Kd[3 * i] * Rrel[j] + Kd[3 * i + 1] * Rrel[3 + j]) + Kd[3 * i + 2] * Rrel[6 + j]
+    M = np.empty(9, np.float32)
+    b = np.empty(3, np.float32)
+    for i in range(3):
+        for j in range(3):
+            M[3 * i + j] = np.float32((A[3 * i] * Ki[j] + A[3 * i + 1] * Ki[3 + j]) + A[3 * i + 2] * Ki[6 + j])
+        b[i] = np.float32((Kd[3 * i] * trel[0] + Kd[3 * i + 1] * trel[1]) + Kd[3 * i + 2] * trel[2])
+    return M, b
+
+
+def normalise_facing(nx, ny, nz):
+    """xnormalise_facing: unit length; planes that do not face the camera become fronto-parallel."""
+    l = np.sqrt(nx * nx + ny * ny + nz * nz)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        il = np.where(l > F(1e-12), F(1.0) / l, F(0.0)).astype(np.float32)
+    nx, ny, nz = nx * il, ny * il, nz * il
+    bad = ~(nz < F(-0.05))
+    return (np.where(bad, F(0), nx).astype(np.float32), np.where(bad, F(0), ny).astype(np.float32),
+            np.where(bad, F(-1), nz).astype(np.float32))
+
+
+class View:
+    """One reference view of a scene with its source views (a Job of the device job table)."""
+
+    def __init__(self, K, K_inv, codes, poses, ref, srcs, patch, stride):
+        self.K = np.asarray(K, np.float32).reshape(3, 3)
+        self.Ki = np.asarray(K_inv, np.float32).reshape(9)
+        self.codes = [np.asarray(c, np.uint8) for c in codes]
+        self.poses = [(np.asarray(R, np.float64).astype(np.float32).reshape(9), np.asarray(t, np.float64).astype(np.float32).reshape(3))
+                      for R, t in poses]
+        self.ref, self.srcs = int(ref), [int(s) for s in srcs]
+        self.H, self.W = self.codes[0].shape
+        self.patch, self.stride = int(patch), int(stride)
+        self.N = (self.patch - 1) // self.stride + 1
+        assert (self.N - 1) * self.stride + 1 == self.patch, "restated for N x N tap windows only"
+        Rr, tr = self.poses[self.ref]
+        self.Mb = [compose(self.K, Rr, tr, *self.poses[s]) for s in self.srcs]
+        self.gray = self.codes[self.ref].astype(np.float32) / F(255.0)
+        ys, xs = np.meshgrid(np.arange(self.H), np.arange(self.W), indexing="ij")
+        self.xs, self.ys = xs.ravel(), ys.ravel()
+
+    # ---------------------------------------------------------------- cost -----
+    def _ray(self, x, y):
+        k = self.Ki
+        fx, fy = x.astype(np.float32), y.astype(np.float32)
+        return fma(k[1], fy, fma(k[0], fx, k[2])), fma(k[4], fy, fma(k[3], fx, k[5]))
+
+    def cost(self, x, y, d, nx, ny, nz):
+        """xcost_t<N, U8 = true> for the pixels (x[i], y[i]) with hypotheses (d[i], n[i])."""
+        H, W, N, st, half = self.H, self.W, self.N, self.stride, self.patch // 2
+        k = self.Ki
+        P = x.shape[0]
+        out = np.full(P, INF, np.float32)
+        inside = (x - half >= 0) & (y - half >= 0) & (x - half + (N - 1) * st < W) & (y - half + (N - 1) * st < H)
+        rpx, rpy = self._ray(x, y)
+        ndr_p = fma(nx, rpx, fma(ny, rpy, nz))
+        live = inside & (ndr_p < F(-1e-6))
+        delta = d * ndr_p
+        w0 = fma(ny, k[3], nx * k[0])
+        w1 = fma(ny, k[4], nx * k[1])
+        w2 = fma(ny, k[5], fma(nx, k[2], nz))
+        stf = F(st)
+        x0 = (x - half).astype(np.float32)
+        y0 = (y - half).astype(np.float32)
+        cx = [x0, x0 + F(N - 1) * stf]
+        cy = [y0, y0 + F(N - 1) * stf]
+        ndr_c = [fma(w0, cx[c & 1], fma(w1, cy[c >> 1], w2)) for c in range(4)]
+        live &= np.maximum(np.maximum(ndr_c[0], ndr_c[1]), np.maximum(ndr_c[2], ndr_c[3])) < F(-1e-6)
+        # reference taps (xref_load): sums in tap order
+        xi = np.clip(x - half, 0, W - 1 - (N - 1) * st)
+        yi = np.clip(y - half, 0, H - 1 - (N - 1) * st)
+        taps = [[self.gray[yi + j * st, xi + i * st] for i in range(N)] for j in range(N)]
+        sr = np.zeros(P, np.float32)
+        srr = np.zeros(P, np.float32)
+        for j in range(N):
+            for i in range(N):
+                sr = sr + taps[j][i]
+                srr = fma(taps[j][i], taps[j][i], srr)
+        INV = F(1.0 / float(N * N))
+        vr = srr - sr * sr * INV
+        fw, fh = F(W - 1), F(H - 1)
+        costs = np.full((6, P), INF, np.float32)
+        n_valid = np.zeros(P, np.int32)
+        with np.errstate(all="ignore"):
+            for s, (M, b) in zip(self.srcs, self.Mb):
+                img = self.codes[s]
+                Hm = [fma(b[r], (w0, w1, w2)[c], delta * M[3 * r + c]) for r in range(3) for c in range(3)]
+                ok = live.copy()
+                for c in range(4):
+                    qx, qy = cx[c & 1], cy[c >> 1]
+                    p0 = fma(Hm[0], qx, fma(Hm[1], qy, Hm[2]))
+                    p1 = fma(Hm[3], qx, fma(Hm[4], qy, Hm[5]))
+                    p2 = fma(Hm[6], qx, fma(Hm[7], qy, Hm[8]))
+                    ok &= p2 < F(0.1) * ndr_c[c]
+                    rz = F(1.0) / p2
+                    u, v = p0 * rz, p1 * rz
+                    ok &= (u >= 0) & (v >= 0) & (u < fw) & (v < fh)
+                sv = np.zeros(P, np.float32)
+                svv = np.zeros(P, np.float32)
+                srv = np.zeros(P, np.float32)
+                for j in range(N):
+                    qy = y0 + F(j) * stf
+                    p0 = fma(Hm[0], x0, fma(Hm[1], qy, Hm[2]))
+                    p1 = fma(Hm[3], x0, fma(Hm[4], qy, Hm[5]))
+                    p2 = fma(Hm[6], x0, fma(Hm[7], qy, Hm[8]))
+                    for i in range(N):
+                        rz = F(1.0) / p2                       # (v_rcp_f32 on the device: 1 ulp)
+                        u, v = p0 * rz, p1 * rz
+                        x0f, y0f = np.floor(u), np.floor(v)
+                        xq = np.clip(np.nan_to_num(x0f, nan=0.0, posinf=0.0, neginf=0.0), 0, W - 2).astype(np.int64)
+                        yq = np.clip(np.nan_to_num(y0f, nan=0.0, posinf=0.0, neginf=0.0), 0, H - 2).astype(np.int64)
+                        fx, fy = u - x0f, v - y0f
+                        t00 = img[yq, xq].astype(np.float32)
+                        t10 = img[yq + 1, xq].astype(np.float32)
+                        t01 = img[yq, xq + 1].astype(np.float32)
+                        t11 = img[yq + 1, xq + 1].astype(np.float32)
+                        top = fma(fx, t01 - t00, t00)
+                        bot = fma(fx, t11 - t10, t10)
+                        sval = fma(fy, bot - top, top)
+                        sv = sv + sval
+                        svv = fma(sval, sval, svv)
+                        srv = fma(taps[j][i], sval, srv)
+                        p0 = fma(stf, Hm[0], p0)
+                        p1 = fma(stf, Hm[3], p1)
+                        p2 = fma(stf, Hm[6], p2)
+                sv = sv * F(1.0 / 255.0)
+                srv = srv * F(1.0 / 255.0)
+                svv = svv * F(1.0 / 65025.0)
+                cov = srv - sr * sv * INV
+                vs = svv - sv * sv * INV
+                den = vr * vs
+                ncc = np.where(den > F(1e-12), cov * (F(1.0) / np.sqrt(den)), F(0.0)).astype(np.float32)
+                c = np.where(ok, F(1.0) - ncc, INF).astype(np.float32)
+                # xsorted_insert for the pixels whose source is valid
+                for j in range(6):
+                    lo, hi = np.minimum(costs[j], c), np.maximum(costs[j], c)
+                    costs[j] = np.where(ok, lo, costs[j])
+                    c = np.where(ok, hi, c)
+                n_valid += ok
+        keep = np.maximum((n_valid + 1) // 2, 2)
+        tot = np.zeros(P, np.float32)
+        with np.errstate(all="ignore"):
+            for j in range(6):
+                tot = tot + np.where(j < keep, costs[j], F(0.0)).astype(np.float32)
+            res = tot / keep.astype(np.float32)
+        good = live & (n_valid >= 2)
+        out[good] = res[good]
+        return out
+
+    def cost_map(self, depth, normal):
+        """Cost of every pixel's plane (amvs_xpm_step, AMVS_XPM_PHASE_EVAL)."""
+        n = normal.reshape(-1, 3)
+        return self.cost(self.xs, self.ys, depth.ravel().astype(np.float32), n[:, 0].copy(), n[:, 1].copy(),
+                         n[:, 2].copy()).reshape(self.H, self.W)
+
+    # ---------------------------------------------------------- view propagation --
+    def view_candidates(self, depth_all, normal_all, s_index, depth_min, depth_max):
+        """xpm_view_candidates_kernel for source index s_index: (cand_depth (H, W) with 0 = none, cand_normal)."""
+        H, W = self.H, self.W
+        M, b = self.Mb[s_index]
+        sv = self.srcs[s_index]
+        Rr, tr = self.poses[self.ref]
+        Rs, ts = self.poses[sv]
+        k = self.Ki
+        x, y = self.xs, self.ys
+        fx, fy = x.astype(np.float32), y.astype(np.float32)
+        d = depth_all[self.ref].ravel()
+        q0 = fma(M[1], fy, fma(M[0], fx, M[2]))
+        q1 = fma(M[4], fy, fma(M[3], fx, M[5]))
+        q2 = fma(M[7], fy, fma(M[6], fx, M[8]))
+        p2 = fma(d, q2, b[2])
+        cd = np.zeros(H * W, np.float32)
+        cn = np.tile(np.array([0, 0, -1], np.float32), (H * W, 1))
+        with np.errstate(all="ignore"):
+            front = p2 > F(0.1)
+            px = np.rint(fma(d, q0, b[0]) / p2)
+            py = np.rint(fma(d, q1, b[1]) / p2)
+            inb = front & (px >= 0) & (px < W) & (py >= 0) & (py < H)
+            pxi = np.where(inb, px, 0).astype(np.int64)
+            pyi = np.where(inb, py, 0).astype(np.int64)
+            d2 = depth_all[sv][pyi, pxi]
+            n0, n1, n2 = (normal_all[sv][pyi, pxi, c] for c in range(3))
+            pxf, pyf = pxi.astype(np.float32), pyi.astype(np.float32)
+            r0 = fma(k[1], pyf, fma(k[0], pxf, k[2]))
+            r1 = fma(k[4], pyf, fma(k[3], pxf, k[5]))
+            dl = d2 * (n0 * r0 + n1 * r1 + n2)
+            nw = [Rs[c] * n0 + Rs[3 + c] * n1 + Rs[6 + c] * n2 for c in range(3)]
+            dw = dl - (n0 * ts[0] + n1 * ts[1] + n2 * ts[2])
+            nr = [Rr[3 * c] * nw[0] + Rr[3 * c + 1] * nw[1] + Rr[3 * c + 2] * nw[2] for c in range(3)]
+            drf = dw + (nr[0] * tr[0] + nr[1] * tr[1] + nr[2] * tr[2])
+            rpx = fma(k[1], fy, fma(k[0], fx, k[2]))
+            rpy = fma(k[4], fy, fma(k[3], fx, k[5]))
+            ndr = nr[0] * rpx + nr[1] * rpy + nr[2]
+            t = drf / ndr
+            okc = inb & (ndr < F(-1e-6)) & (t >= F(depth_min)) & (t <= F(depth_max))
+            fnx, fny, fnz = normalise_facing(nr[0], nr[1], nr[2])
+        cd[okc] = t[okc]
+        cn[okc, 0], cn[okc, 1], cn[okc, 2] = fnx[okc], fny[okc], fnz[okc]
+        return cd.reshape(H, W), cn.reshape(H, W, 3)
+
+    # ---------------------------------------------------------------- half sweep --
+    def half_sweep(self, depth, normal, cost, cand_d, cand_n, colour, iteration, seed, rng_fill, depth_min, depth_max,
+                   num_refine=2, view_propagation=True):
+        """xpm_sweep_kernel for one checkerboard colour, in place semantics: returns new (depth, normal, cost).
+        rng_fill(seed, view, draw, n) -> (uniform (n,), normals (n, 3)) of the build's counter-hash generator."""
+        H, W = self.H, self.W
+        D, Nn, C = depth.copy(), normal.copy(), cost.copy()
+        sel = ((self.xs + self.ys + colour) & 1) == 0               # x = 2 k + ((y + colour) & 1)
+        x, y = self.xs[sel], self.ys[sel]
+        idx = y * W + x
+        bd = D.ravel()[idx].copy()
+        bn = [Nn.reshape(-1, 3)[idx, c].copy() for c in range(3)]
+        bc = C.ravel()[idx].copy()
+        rpx, rpy = self._ray(x, y)
+        shrink = 0.5 ** iteration
+        rel_range, nrm_range = F(max(0.2 * shrink, 0.004)), F(max(0.4 * shrink, 0.01))
+        with_random = iteration < 2
+        draw = 1 + 2 * iteration + colour
+        n_hyp = 6 + num_refine + (1 if with_random else 0)
+        dmin, dmax = F(depth_min), F(depth_max)
+        for hyp in range(n_hyp):
+            d, nx, ny, nz = bd.copy(), bn[0].copy(), bn[1].copy(), bn[2].copy()
+            have = np.ones(x.shape[0], bool)
+            with np.errstate(all="ignore"):
+                if hyp == 0:
+                    have = ~(bc < INF)
+                elif hyp <= 4:
+                    k = hyp - 1
+                    xx = x + (-1 if k == 0 else (1 if k == 1 else 0))
+                    yy = y + (-1 if k == 2 else (1 if k == 3 else 0))
+                    have = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+                    j = np.where(have, yy * W + xx, 0)
+                    nd = depth.ravel()[j]
+                    nx, ny, nz = (normal.reshape(-1, 3)[j, c] for c in range(3))
+                    rqx, rqy = self._ray(np.where(have, xx, 0), np.where(have, yy, 0))
+                    dl = nd * (nx * rqx + ny * rqy + nz)
+                    ndr = nx * rpx + ny * rpy + nz
+                    have = have & (ndr < F(-1e-6))
+                    d = dl / ndr
+                elif hyp == 5:
+                    have = np.full(x.shape[0], bool(view_propagation))
+                    d = cand_d.ravel()[idx]
+                    have = have & (d > 0)
+                    nx, ny, nz = (cand_n.reshape(-1, 3)[idx, c] for c in range(3))
+                elif hyp < 6 + num_refine:
+                    r = hyp - 6
+                    u, g = rng_fill(seed, self.ref, draw * 8 + r, H * W)
+                    u, g = u[idx], g[idx]
+                    scale = F(1.0 if r == 0 else 0.25)
+                    d = bd * (F(1.0) + (u * F(2.0) - F(1.0)) * rel_range * scale)
+                    nx = bn[0] + g[:, 0] * nrm_range * scale
+                    ny = bn[1] + g[:, 1] * nrm_range * scale
+                    nz = bn[2] + g[:, 2] * nrm_range * scale
+                    nx, ny, nz = normalise_facing(nx, ny, nz)
+                else:
+                    u, g = rng_fill(seed, self.ref, draw * 8 + 7, H * W)
+                    u, g = u[idx], g[idx]
+                    lmin, lmax = np.log(dmin), np.log(dmax)
+                    nx, ny, nz = normalise_facing(g[:, 0] * F(0.3), g[:, 1] * F(0.3), np.full(x.shape[0], F(-1.0)))
+                    d = np.exp(lmin + u * (lmax - lmin)).astype(np.float32)
+                if hyp > 0:
+                    have = have & (d >= dmin) & (d <= dmax)
+            d = d.astype(np.float32)
+            c = self.cost(x, y, np.where(have, d, F(1.0)).astype(np.float32), np.asarray(nx, np.float32),
+                          np.asarray(ny, np.float32), np.asarray(nz, np.float32))
+            take = have & ((hyp == 0) | (c < bc))
+            bc = np.where(take, c, bc).astype(np.float32)
+            bd = np.where(take, d, bd).astype(np.float32)
+            bn = [np.where(take, v, o).astype(np.float32) for v, o in zip((nx, ny, nz), bn)]
+        D.ravel()[idx] = bd
+        for c3 in range(3):
+            Nn.reshape(-1, 3)[idx, c3] = bn[c3]
+        C.ravel()[idx] = bc
+        return D, Nn, C
