@@ -24,7 +24,10 @@ class PmParams(C.Structure):
                 ("num_samples", C.c_int32), ("tile_rows", C.c_int32), ("views_per_launch", C.c_int32),
                 ("depth_min", C.c_float), ("depth_max", C.c_float),
                 ("log_depth_scale", C.c_float), ("log_depth_min", C.c_float), ("mode", C.c_int32),
-                ("schedule", C.c_int32)]
+                ("schedule", C.c_int32), ("first_iteration", C.c_int32), ("flags", C.c_int32)]
+
+
+PM_NO_CONFIDENCE = 1
 
 
 class XpmParams(C.Structure):

@@ -83,6 +83,11 @@ struct amvs_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int last_tile_rows = 0, last_views_per_launch = 0;
+    // state a continuation call (amvs_pm_params.first_iteration > 0) resumes: which depth buffer is
+    // current, the next iteration, and a fingerprint of the batch it belongs to
+    bool pm_resumable = false;
+    int pm_cur = 0, pm_next_iteration = 0;
+    uint64_t pm_key = 0;
     // amvs_set_step_tuning: strip rows / resident workgroups per CU by [iteration][0 = propagation, 1 = refinement]
     // (0 = automatic); iterations beyond the table use its last row
     std::vector<int> tune_rows, tune_cap;
@@ -439,7 +444,7 @@ struct SchedStep {
 std::vector<SchedStep> build_schedule(const amvs_pm_params *p)
 {
     std::vector<SchedStep> v;
-    for (int it = 0; it < p->num_iterations; ++it) {
+    for (int it = p->first_iteration; it < p->first_iteration + p->num_iterations; ++it) {
         // _spatial_propagation (mvs_patchmatch.py:415-457): even iterations pull from
         // (y+1,x) then (y,x+1), odd iterations from (y-1,x) then (y,x-1)
         const int sgn = (it % 2 == 0) ? 1 : -1;
@@ -463,7 +468,7 @@ void apply_step(amvs::StepArgs &a, const SchedStep &st)
 // One stream: the batch in groups of `vpl` views, each group through the whole schedule with the
 // fused kernel (sampling + window sums + selection in one launch).
 int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *p, uint64_t seed, int fast,
-                       const std::vector<SchedStep> &sched, void *conf_dev)
+                       const std::vector<SchedStep> &sched, void *conf_dev, int cur0, bool do_init, bool do_conf)
 {
     const size_t hw = (size_t)c->H * c->W;
     // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
@@ -506,10 +511,11 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;
-        int cur = 0;
-        // initialisation (mvs_patchmatch.py:268-284)
-        HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
-                                    c->d_depth[cur], c->d_normal[0], c->d_cost[0], c->stream));
+        int cur = cur0;
+        // initialisation (mvs_patchmatch.py:268-284); a continuation call resumes the context's state
+        if (do_init)
+            HIPCHK(c, amvs::launch_init(a.jobs, nj, (long long)hw, seed, p->log_depth_scale, p->log_depth_min,
+                                        c->d_depth[cur], c->d_normal[0], c->d_cost[0], c->stream));
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g], c->stream));
         if (c->step_timing) HIPCHK(c, hipEventRecord(c->ev_steps[c->n_step_events++], c->stream));
         for (size_t i = 0; i < sched.size(); ++i) {
@@ -528,10 +534,12 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         a.wg_cap = 0;
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 1], c->stream));
         // _compute_confidence (mvs_patchmatch.py:493-534), written straight into the output
-        a.mode = amvs::MODE_CONF;
-        set_io(a, c, cur);
-        a.aux = conf_dev ? (float *)conf_dev : c->d_aux;
-        HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+        if (do_conf) {
+            a.mode = amvs::MODE_CONF;
+            set_io(a, c, cur);
+            a.aux = conf_dev ? (float *)conf_dev : c->d_aux;
+            HIPCHK(c, amvs::launch_step(p->patch_size, n_src, a, c->stream));
+        }
         HIPCHK(c, hipEventRecord(c->ev_groups[3 * g + 2], c->stream));
     }
     c->timing.sweep_launches = launches;
@@ -962,16 +970,37 @@ static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if (p->schedule < 0 || p->schedule > AMVS_SCHEDULE_SPLIT) return fail(c, AMVS_EINVAL, "unknown schedule");
     if (p->schedule == AMVS_SCHEDULE_SPLIT && !fast)
         return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists in fast mode only");
+    // Continuation: iterations first_iteration .. of a sweep whose earlier iterations a previous call ran
+    // on the same batch; the state maps stay in the context between the calls.
+    if (p->first_iteration < 0) return fail(c, AMVS_EINVAL, "negative first_iteration");
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    mix((uint64_t)n_ref); mix((uint64_t)n_src); mix((uint64_t)p->patch_size); mix((uint64_t)p->num_samples); mix(seed);
+    mix((uint64_t)fast); mix((uint64_t)__builtin_bit_cast(uint32_t, p->depth_min)); mix((uint64_t)__builtin_bit_cast(uint32_t, p->depth_max));
+    for (int i = 0; i < n_ref; ++i) mix((uint64_t)(uint32_t)ref_ids[i]);
+    for (int i = 0; i < n_ref * n_src; ++i) mix((uint64_t)(uint32_t)src_ids[i]);
+    const bool resume = p->first_iteration > 0;
+    if (resume) {
+        if (p->schedule == AMVS_SCHEDULE_SPLIT) return fail(c, AMVS_EUNSUPPORTED, "the split schedule cannot resume a sweep");
+        if (!c->pm_resumable || c->pm_key != key || c->pm_next_iteration != p->first_iteration)
+            return fail(c, AMVS_EINVAL, "first_iteration > 0 continues the previous call: same batch, sources, patch, samples, "
+                                        "seed and depth range, and first_iteration = the iterations already run");
+    }
+    c->pm_resumable = false;
     resolve_timing(c);
     c->timing = amvs_timing{};
     const std::vector<SchedStep> sched = build_schedule(p);
-    int cur = 0;
+    const int cur0 = resume ? c->pm_cur : 0;
+    int cur = cur0;
     for (const SchedStep &st : sched) cur ^= st.flip_d;                           // final depth buffer
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (p->schedule == AMVS_SCHEDULE_SPLIT) {
         if ((rc = run_split_schedule(c, n_ref, n_src, p, seed, sched, conf_dev))) return rc;
     } else {
-        if ((rc = run_fused_schedule(c, n_ref, n_src, p, seed, fast, sched, conf_dev))) return rc;
+        if ((rc = run_fused_schedule(c, n_ref, n_src, p, seed, fast, sched, conf_dev, cur0, !resume,
+                                     (p->flags & AMVS_PM_NO_CONFIDENCE) == 0))) return rc;
+        c->pm_resumable = true; c->pm_cur = cur; c->pm_key = key;
+        c->pm_next_iteration = p->first_iteration + p->num_iterations;
     }
     // every group ran the same schedule, so the final depth buffer is the same for all
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -24,15 +24,17 @@ def _ids(a):
 
 
 def make_pm_params(patch_size, num_iterations, num_samples, depth_min, depth_max, tile_rows=0,
-                   views_per_launch=0, mode="default", schedule="auto"):
+                   views_per_launch=0, mode="default", schedule="auto", first_iteration=0, confidence=True):
     """amvs_pm_params with the log-range formed in double as mvs_patchmatch.py:268-271 does.
-    mode: "default" (the engine's), "exact" or "fast" (include/amvs.h AMVS_MODE_*)."""
+    mode: "default" (the engine's), "exact" or "fast" (include/amvs.h AMVS_MODE_*).
+    first_iteration > 0 continues the previous call's sweep (include/amvs.h); confidence=False skips the
+    confidence pass of this call."""
     log_min = np.log(float(depth_min))
     log_max = np.log(float(depth_max))
     return PmParams(int(patch_size), int(num_iterations), int(num_samples), int(tile_rows),
                     int(views_per_launch), float(depth_min), float(depth_max),
                     float(np.float32(log_max - log_min)), float(np.float32(log_min)), _lib.MODES[mode],
-                    _lib.SCHEDULES[schedule])
+                    _lib.SCHEDULES[schedule], int(first_iteration), 0 if confidence else _lib.PM_NO_CONFIDENCE)
 
 
 def make_xpm_params(patch_size, depth_min, depth_max, window_stride=2, num_refine=2, view_propagation=True,

@@ -166,6 +166,11 @@ def main():
     ap.add_argument("--no-planesweep", action="store_true", help="skip the plane-sweep sub-record")
     ap.add_argument("--fusion", action="store_true",
                     help="fuse + filter the gathered maps inside every timed step (BASELINE config 5)")
+    ap.add_argument("--gather-per-iteration", action="store_true",
+                    help="parity mode with north_star's exchange pattern: the sweep runs one iteration per call "
+                         "(amvs_pm_params.first_iteration) and the ranks all-gather the depth / normal maps after EVERY "
+                         "iteration (the gather of iteration i under the sweep of iteration i+1; the maps do not feed "
+                         "back -- the reference has no view propagation -- so the results are those of the default run)")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5 preset: 64 views of 3840x2160 over the ranks, fusion inside the step")
     args = ap.parse_args()
@@ -251,6 +256,8 @@ def main():
     # PatchMatchMVS.reconstruct pays (its last group's gather is exposed).
     nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 2) else 1)
     nb = max(1, min(nb, n_loc))
+    if args.gather_per_iteration:
+        nb = 1                                  # a continuation call resumes the state of ONE batch
     bounds = [(b * n_loc) // nb for b in range(nb + 1)]
     comm_stream = torch.cuda.Stream(device=dev)
     gdev = dev if backend == "nccl" else torch.device("cpu")
@@ -334,6 +341,72 @@ def main():
         if args.fusion and rank == 0:
             fuse(k)
 
+    # --gather-per-iteration: one call per iteration; intermediate maps (depth, normal) alternate between
+    # two buffer sets, each gathered on the comm stream while the next iteration is swept
+    if args.gather_per_iteration:
+        it_params = [make_pm_params(args.patch, 1, args.samples, sc.depth_min, sc.depth_max, args.tile_rows,
+                                    args.views_per_launch, schedule=args.schedule, first_iteration=it,
+                                    confidence=it == args.iters - 1) for it in range(args.iters)]
+        it_d = torch.empty((2, n_loc, H * W), dtype=torch.float32, device=dev)
+        it_n = torch.empty((2, n_loc, 3 * H * W), dtype=torch.float32, device=dev)
+        it_full = [dict(d=torch.empty((world * n_loc, H * W), dtype=torch.float32, device=gdev),
+                        n=torch.empty((world * n_loc, 3 * H * W), dtype=torch.float32, device=gdev)) for _ in range(2)] \
+            if world > 1 else None
+        it_gathered = [None, None]
+        state["it_gathers"] = 0
+
+    def step_per_iteration():
+        k = state["step"] % nbuf
+        state["step"] += 1
+        works = []
+        if world > 1 and gathered[k] is not None:
+            stream.wait_event(gathered[k])
+        for it in range(args.iters):
+            last = it == args.iters - 1
+            j = it % 2
+            if not last and it_gathered[j] is not None:
+                stream.wait_event(it_gathered[j])         # the exchange that read this set two iterations ago
+            outs = (depth[k], normal[k], conf[k]) if last else (it_d[j], it_n[j], conf[k])
+            eng.patchmatch_device(refs, srcs, it_params[it], 42, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
+            if world == 1:
+                continue
+            done = torch.cuda.Event()
+            done.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(done)
+                if last:
+                    pairs = [(full[k]["d"].view(world * n_loc, -1), depth[k].reshape(n_loc, -1)),
+                             (full[k]["n"].view(world * n_loc, -1), normal[k].reshape(n_loc, -1)),
+                             (full[k]["c"].view(world * n_loc, -1), conf[k].reshape(n_loc, -1))]
+                else:
+                    pairs = [(it_full[j]["d"], it_d[j]), (it_full[j]["n"], it_n[j])]
+                mine_works = []
+                for out_t, inp in pairs:
+                    if backend != "nccl":
+                        comm_stream.synchronize()
+                        inp = inp.cpu()
+                    mine_works.append(dist.all_gather_into_tensor(out_t, inp, async_op=True))
+                if backend == "nccl":
+                    for w in mine_works:
+                        w.wait()                         # comm_stream waits, not the host
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+                if last:
+                    gathered[k] = ev
+                else:
+                    it_gathered[j] = ev
+                    state["it_gathers"] += 1
+                works += mine_works
+        eng.sync()
+        if world > 1:
+            in_flight.append(works)
+            drain(keep_last_step=not args.fusion)
+        if args.fusion and rank == 0:
+            fuse(k)
+
+    if args.gather_per_iteration:
+        step = step_per_iteration                           # noqa: F811
+
     def fence():
         drain(keep_last_step=False)
         if world > 1:
@@ -353,9 +426,12 @@ def main():
     for _ in range(args.steps):
         step()
         t = eng.timing()
-        sweep_ms += t["sweep_ms"] * nb            # timing of the last batch; batches are equal-sized
+        # timing of the last call: batches are equal-sized; with one call per iteration, iterations are
+        # not (early ones scatter more), so the roofline figure of that mode is the LAST iteration's
+        calls = nb * (args.iters if args.gather_per_iteration else 1)
+        sweep_ms += t["sweep_ms"] * calls
         conf_ms += t["confidence_ms"] * nb
-        launches += t["sweep_launches"] * nb
+        launches += t["sweep_launches"] * calls
     fence()
     elapsed = time.perf_counter() - t0
     # one step from an idle pipeline, its exchange (and fusion) inside: the latency of one reconstruct
@@ -413,6 +489,8 @@ def main():
                        "iters": args.iters, "samples": args.samples, "sources": S, "arithmetic": args.mode,
                        "sampling": eng.sampling_mode(), "tile_rows": eng.last_tile_rows(), "views_per_launch": eng.last_views_per_launch(),
                        "schedule": args.schedule, "batches_per_step": nb,
+                       "exchange": ("depth + normal maps after every iteration, depth + normal + confidence after the last"
+                                    if args.gather_per_iteration else "depth + normal + confidence maps once per sweep"),
                        "pixel_hypotheses_per_step": n_hyp_step},
             "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

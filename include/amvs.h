@@ -69,7 +69,17 @@ typedef struct {
                                  strips, 3 = split (fast mode only: sampling kernel + window kernel,
                                  pipelined over view groups).  Performance only; results do not
                                  depend on it.                                          */
+    int32_t first_iteration;  /* 0: a new sweep (random initialisation, mvs_patchmatch.py:268-284).
+                                 k > 0: CONTINUE the sweep of the previous PatchMatch call of this context
+                                 -- same batch, sources, patch, samples, seed, depth range -- with
+                                 iterations k .. k + num_iterations - 1 of the schedule (:287-308); k must
+                                 equal the iterations already run.  A sweep run one iteration per call
+                                 returns the maps of one call bit for bit; the outputs of every call are
+                                 the maps as they stand (what a per-iteration exchange gathers).   */
+    int32_t flags;            /* AMVS_PM_NO_CONFIDENCE: skip the confidence pass (conf output untouched) */
 } amvs_pm_params;
+
+#define AMVS_PM_NO_CONFIDENCE 1
 
 #define AMVS_SCHEDULE_AUTO        0
 #define AMVS_SCHEDULE_VIEW_MAJOR  1

@@ -212,3 +212,41 @@ def test_strip_orders_give_identical_maps(mode):
     for schedule in maps:
         for a, b, what in zip(maps["view-major"], maps[schedule], ("depth", "normal", "confidence")):
             _eq(b, a, f"{mode} {schedule} {what}")
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+@pytest.mark.parametrize("entry", ["host", "device"])
+def test_sweep_continued_one_iteration_per_call(scene_a, mode, entry):
+    """amvs_pm_params.first_iteration: a sweep run as one call per iteration (the confidence pass only in
+    the last) returns the maps of the single call bit for bit -- through the host-buffer entry point
+    (which resolves the state in place between the calls) and the device one -- and a continuation that
+    does not match the previous call is refused.  This is what bench.py --gather-per-iteration runs."""
+    import torch
+
+    import amvs
+    from amvs.engine import make_pm_params
+    sc = scene_a
+    refs, srcs = [2, 1], [[1, 3, 0, 4], [0, 2, 3, 4]]
+    iters, samples = 3, 4
+
+    def run(eng, **kw):
+        p = make_pm_params(7, kw.pop("n", iters), samples, sc.depth_min, sc.depth_max, **kw)
+        if entry == "host":
+            return eng.patchmatch(refs, srcs, p, 9)
+        dev = torch.device("cuda", 0)
+        out = [torch.zeros((2, sc.H * sc.W * k), dtype=torch.float32, device=dev) for k in (1, 3, 1)]
+        torch.cuda.synchronize()
+        eng.patchmatch_device(refs, srcs, p, 9, *[t.data_ptr() for t in out])
+        eng.sync()
+        return tuple(t.cpu().numpy() for t in out)
+
+    with sc.engine(mode) as eng:
+        whole = run(eng)
+        for it in range(iters):
+            last = run(eng, n=1, first_iteration=it, confidence=it == iters - 1)
+        for a, b, what in zip(whole, last, ("depth", "normal", "confidence")):
+            _eq(b.reshape(a.shape), a, f"{mode} {entry} {what} after {iters} one-iteration calls")
+        with pytest.raises(amvs.AmvsError):
+            run(eng, n=1, first_iteration=1)                     # 3 iterations were run, not 1
+        with pytest.raises(amvs.AmvsError):
+            eng.patchmatch([2], [[1, 3, 0, 4]], make_pm_params(7, 1, samples, sc.depth_min, sc.depth_max, first_iteration=3), 9)

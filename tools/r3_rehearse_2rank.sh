@@ -1,0 +1,9 @@
+#!/bin/bash
+# Rehearsal of the N=2 bench path on a one-GPU box: two ranks on cuda:0, gloo transport (the real run is
+# one rank per GPU over RCCL, launched by the driver).  Default exchange, then --gather-per-iteration.
+set -o pipefail
+export AMVS_BENCH_BACKEND=gloo AMVS_BENCH_ONE_DEVICE=1 HSA_ENABLE_IPC_MODE_LEGACY=0
+for extra in "" "--gather-per-iteration"; do
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 \
+    bench.py --gpus 2 --steps 2 --warmup 1 --scene-views ${VIEWS:-8} --no-planesweep $extra 2>&1 | grep -v "amdgpu.ids\|OMP_NUM\|^\*\*\*" || exit 1
+done
