@@ -1175,8 +1175,12 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.H = c->H; a.W = c->W;
     // tall strips (little halo re-sampling); the planes are chunked so that the launch still has
     // about four strips per resident wave slot
-    a.TH = AMVS_SWEEP_MAX_TH < c->H ? AMVS_SWEEP_MAX_TH : c->H;
-    if (c->sweep_tile_rows >= 1 && c->sweep_tile_rows <= AMVS_SWEEP_MAX_TH && c->sweep_tile_rows < a.TH)
+    // (the fewest bands of at most AMVS_SWEEP_MAX_TH rows, evenly high: 720 rows -> 12 bands of 60)
+    {
+        const int bands = (c->H + AMVS_SWEEP_MAX_TH - 1) / AMVS_SWEEP_MAX_TH;
+        a.TH = (c->H + bands - 1) / bands;
+    }
+    if (c->sweep_tile_rows >= 1 && c->sweep_tile_rows <= AMVS_SWEEP_MAX_TH && c->sweep_tile_rows < c->H)
         a.TH = c->sweep_tile_rows;
     a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
     a.tiles_y = (c->H + a.TH - 1) / a.TH;

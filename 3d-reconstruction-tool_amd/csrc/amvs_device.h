@@ -470,8 +470,11 @@ AMVS_DEV void fill_gray_lut(float *lut, int lane)
     __syncthreads();
 }
 
-// lane i <- lane i+1 (whole-wave shift; lane 63 receives 0).  hipcc folds this
-// into the consuming VALU op as `v_add_f32_dpp ... wave_shl:1`.
+// lane i <- lane i+1 (whole-wave shift; lane 63 receives 0).  hipcc folds this into the consuming VALU
+// op as `v_add_f32_dpp ... wave_shl:1`.  (Keeping the shift a v_mov_b32_dpp of its own -- in isolation
+// mov_dpp 1.84 ns + add 0.95 ns against 3.26 ns for the folded add, tools/valu_rate.hip -- was measured
+// in the kernels in round 3: plane sweep 61.7 against 68.6 G px-hyp/s, pm_step 40.7 against 41.5: the
+// folded form stays.)
 AMVS_DEV float wave_shl1(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));

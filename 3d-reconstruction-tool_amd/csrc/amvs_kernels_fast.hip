@@ -122,7 +122,9 @@ AMVS_DEV FastCol fast_column_terms(MP M, float fx)
     return c;
 }
 
-template <bool LEAN, bool BOUNDED, class MP, class BP>
+// TRACK: collect min / max |z| for the caller's range test (the plane sweep decides once per strip and
+// plane instead, see plane_sweep_fast_kernel).
+template <bool LEAN, bool BOUNDED, bool TRACK, class MP, class BP>
 AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, const FastCol &col, float fy, float d, bool &valid,
                            float &zlo, float &zhi)
 {
@@ -137,9 +139,11 @@ AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, const FastCol &col,
     if constexpr (LEAN) {
         rz = __builtin_amdgcn_rcpf(zz);
         rz = __builtin_fmaf(rz, __builtin_fmaf(-zz, rz, 1.0f), rz);
-        const float az = __builtin_fabsf(zz);
-        zlo = __builtin_fminf(zlo, az);
-        zhi = __builtin_fmaxf(zhi, az);
+        if constexpr (TRACK) {
+            const float az = __builtin_fabsf(zz);
+            zlo = __builtin_fminf(zlo, az);
+            zhi = __builtin_fmaxf(zhi, az);
+        }
     } else {
         rz = 1.0f / zz;
     }
@@ -190,7 +194,7 @@ AMVS_DEV void fast_columns(JobCP job, float fx, FastCol (&cols)[S])
     for (int s = 0; s < S; ++s) cols[s] = fast_column_terms(job->fsrc[s].M, fx);
 }
 
-template <int S, bool LEAN, bool BOUNDED>
+template <int S, bool LEAN, bool BOUNDED, bool TRACK = LEAN>
 AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, const FastCol (&cols)[S], float fy, float d,
                                       bool live, float (&v)[S], bool &ok)
 {
@@ -208,11 +212,11 @@ AMVS_DEV unsigned fast_sample_sources(JobCP job, const FastConsts &fc, const Fas
         for (int i = 0; i < 3; ++i) b[i] = jr->fsrc[s].b[i];
         const unsigned long long img = jr->fsrc[s].pairs;
         bool valid;
-        tg[s] = fast_geom<LEAN, BOUNDED>(M, b, fc, cols[s], fy, d, valid, zlo, zhi);
+        tg[s] = fast_geom<LEAN, BOUNDED, TRACK>(M, b, fc, cols[s], fy, d, valid, zlo, zhi);
         okbits |= valid ? (1u << s) : 0u;
         raw[s] = fast_load(img, tg[s].off);
     }
-    if constexpr (LEAN) ok = (zlo >= 0x1p-95f) & (zhi < 0x1p96f);
+    if constexpr (LEAN && TRACK) ok = (zlo >= 0x1p-95f) & (zhi < 0x1p96f);
 #pragma unroll
     for (int s = 0; s < S; ++s) v[s] = fast_finish(raw[s], tg[s], live);
     return okbits;
@@ -633,8 +637,29 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
 
     for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
 
+    // The lean reciprocal (v_rcp_f32 + one FMA) equals 1.0f / z wherever 2^-95 <= |z| < 2^96
+    // (amvs_device.h).  For a plane, z = fma(depth, fma(M7, y, t2), b2) + 1e-8 is monotonic along a
+    // lane's column, so the test is made ONCE per strip and plane at the strip's first and last row
+    // (same sign at both ends: no zero crossing inside) instead of in every row; a strip that fails runs
+    // its rows with the IEEE quotient -- the same values either way (measured +2 %: 61.7 against 60.5
+    // G px-hyp/s in one run).
+    const float fy_first = (float)(y0 - HALF), fy_last = (float)(y0 - HALF + rows - 1);
+
     for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[d];
+        bool lean_ok = true;
+        {
+            JobCP jr = reload(job);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float m7 = jr->fsrc[s].M[7], b2 = jr->fsrc[s].b[2];
+                const float z0 = __builtin_fmaf(depth, __builtin_fmaf(m7, fy_first, cols[s].t2), b2) + 1e-8f;
+                const float z1 = __builtin_fmaf(depth, __builtin_fmaf(m7, fy_last, cols[s].t2), b2) + 1e-8f;
+                const float a0 = __builtin_fabsf(z0), a1 = __builtin_fabsf(z1);
+                lean_ok &= (a0 >= 0x1p-95f) & (a0 < 0x1p96f) & (a1 >= 0x1p-95f) & (a1 < 0x1p96f) & ((z0 > 0.0f) == (z1 > 0.0f));
+            }
+        }
+        const bool lean_strip = __all(lean_ok);
         uint32_t rb[RefBytes<K>::NB];
         float ring_v[FRing<S>::NR][K];
         typename Hist<K, S>::T hist_ok = 0;
@@ -653,7 +678,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
             const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
             float v[S];
-            const unsigned okbits = fast_sample_sources_checked<S, false>(job, fc, cols, (float)yr, depth, live, v);
+            bool unused_ok = true;
+            const unsigned okbits = lean_strip
+                ? fast_sample_sources<S, true, false, false>(job, fc, cols, (float)yr, depth, live, v, unused_ok)
+                : fast_sample_sources<S, false, false, false>(reload(job), fc, cols, (float)yr, depth, live, v, unused_ok);
             ref_bytes_push<K>(rb, rcode);
             fring_push<K, S>(lring, lane, wslot, ring_v, v);
             wslot = wslot + 1 == K ? 0 : wslot + 1;
