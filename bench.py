@@ -74,6 +74,33 @@ def profiled_traffic(kernel_key, workload_key):
     return None
 
 
+# Issue cost of one VALU wave-instruction per SIMD, measured on MI355X at 8 waves per SIMD with
+# tools/valu_rate.hip (gpurun_out/r2_valu_rate.log): v_add_f32 / v_fma_f32 0.95-1.16 ns, v_add_f32_dpp
+# wave_shl:1 (the row sums' cross-lane adds) 3.26 ns.  1 024 SIMDs per MI355X.
+VALU_PLAIN_NS, VALU_DPP_NS, N_SIMDS = 0.95, 3.26, 1024
+
+
+def valu_issue_roofline(kernel_key, workload_key, dpp_insts, launch_ms):
+    """The VALU-ISSUE roofline of a kernel that is not memory-bound (the plane sweep: L2 hit rate 0.985, its
+    sources never leave L2): wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU,
+    profiles/traffic.json), the cross-lane DPP adds among them counted from the launch shape, each kind
+    priced with its measured issue cost, spread over the chip's SIMDs -> the time the VALU pipes alone
+    need, and the fraction of the measured launch it explains.  None without a matching profile."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f).get(kernel_key)
+        if not e or e.get("workload") != workload_key or e.get("source_hash") != kernel_source_hash(kernel_key):
+            return None
+        valu = float(e["sq_insts_valu"])
+    except (OSError, ValueError, KeyError):
+        return None
+    plain = max(valu - dpp_insts, 0.0)
+    floor_ms = (plain * VALU_PLAIN_NS + dpp_insts * VALU_DPP_NS) / N_SIMDS * 1e-6
+    return {"bound": "valu-issue", "valu_wave_instructions_per_launch": int(valu), "of_which_dpp": int(dpp_insts),
+            "issue_ns": {"plain": VALU_PLAIN_NS, "dpp": VALU_DPP_NS}, "simds": N_SIMDS,
+            "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / launch_ms, 3) if launch_ms > 0 else None}
+
+
 def host_cores():
     """CPU threads this process may really use: the cgroup quota if there is one (a GPU box exposes
     every host core but grants a share), else the affinity mask, else os.cpu_count()."""
@@ -607,6 +634,12 @@ def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
                         "traffic": profiled_traffic(kname, f"{n_views}x{W}x{H}"),
                         "algorithmic_bytes_per_launch": int(bytes_per_hyp * n_hyp),
                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": steps}}
+    # the HBM ruler does not describe this kernel (traffic << algorithmic bytes): its VALU-issue roofline
+    th, half = eng.last_tile_rows(), patch // 2
+    tiles_x = -(-W // (64 - 2 * half))
+    strip_rows = sum(min(th, H - y) + 2 * half for y in range(0, H, th))
+    dpp = 3 * S * (patch - 1) * n_views * tiles_x * strip_rows * D
+    out["valu_roofline"] = valu_issue_roofline(kname, f"{n_views}x{W}x{H}", dpp, launch_ms)
     if with_cpu:
         oracle.set_threads(host_cores())
         r = n_views // 2

@@ -65,6 +65,51 @@ for name in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     for k, v in acc.items():
         vals[k] = sum(v) / len(v)
         out.append(f"pmc[{name}] {KF}* {k}: mean_per_launch={sum(v)/len(v):.6g} n={len(v)}")
+# split by launch kind and iteration: the sweep's dispatches come in schedule order -- per step and
+# view group, per iteration 2 propagation launches (template argument 1) and `samples` refinement
+# launches (argument 2) -- so the n-th propagation dispatch belongs to iteration (n // 2) % iters, the
+# n-th refinement dispatch to iteration (n // samples) % iters
+ITERS, SAMPLES = int(os.environ.get("PM_ITERS", "8")), int(os.environ.get("PM_SAMPLES", "8"))
+
+
+def kind_of(name):
+    m = name.split(KF)[1].split(">")[0].split(",") if KF in name else []
+    return {"1": "PROP", "2": "REFINE"}.get(m[2].strip(), None) if len(m) > 2 else None
+
+
+def by_iteration(rows, value):
+    """rows in dispatch order -> {kind: [mean per iteration]}"""
+    seq = collections.defaultdict(list)
+    for r in rows:
+        k = kind_of(r["Kernel_Name"])
+        if k:
+            seq[k].append(value(r))
+    out_ = {}
+    for k, v in seq.items():
+        per = 2 if k == "PROP" else SAMPLES
+        acc = [[] for _ in range(ITERS)]
+        for n, x in enumerate(v):
+            acc[(n // per) % ITERS].append(x)
+        out_[k] = [sum(a) / len(a) if a else float("nan") for a in acc]
+    return out_
+
+
+if tr:
+    rows = sorted((r for r in csv.DictReader(open(tr)) if KF in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    for k, v in by_iteration(rows, lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6).items():
+        out.append(f"{KF}* {k} mean ms by iteration: " + " ".join(f"{x:.3f}" for x in v))
+for name in ("pmc_sq", "pmc_write", "pmc_fetch"):
+    f = latest(f"{PROF}/{name}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    rows = [r for r in csv.DictReader(open(f)) if KF in r["Kernel_Name"]]
+    for cname in sorted({r["Counter_Name"] for r in rows}):
+        if cname not in ("SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "TCC_HIT_sum", "TCC_MISS_sum",
+                         "FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        sel = sorted((r for r in rows if r["Counter_Name"] == cname), key=lambda r: int(r["Dispatch_Id"]))
+        for k, v in by_iteration(sel, lambda r: float(r["Counter_Value"])).items():
+            out.append(f"pmc[{name}] {cname} {k} by iteration: " + " ".join(f"{x:.4g}" for x in v))
 if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals:
     out.append(f"L2 hit rate {vals['TCC_HIT_sum']/(vals['TCC_HIT_sum']+vals['TCC_MISS_sum']):.3f}; "
                f"misses are 128-byte lines: {vals['TCC_MISS_sum']*128/1e9:.2f} GB per launch from the fabric "
@@ -77,7 +122,7 @@ if workload_key and "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     from bench import kernel_source_hash            # the counters belong to THESE kernel sources
     t[kernel_key] = {"workload": workload_key, "fetch_kib": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"],
                      "fetch_correction": 2.0, "source": tag, "source_hash": kernel_source_hash(kernel_key)}
-    for extra in ("TCC_HIT_sum", "TCC_MISS_sum"):
+    for extra in ("TCC_HIT_sum", "TCC_MISS_sum", "SQ_INSTS_VALU"):
         if extra in vals:
             t[kernel_key][extra.lower()] = vals[extra]
     json.dump(t, open(path, "w"), indent=1)
