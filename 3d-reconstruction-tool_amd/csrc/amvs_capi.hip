@@ -291,13 +291,17 @@ int resolve_fast(amvs_ctx *c, int requested, int *fast)
     return AMVS_OK;
 }
 
-// Views swept together by one launch.  Measured on MI355X (16 views 1080p, k=7, S=4, G px-hyp/s):
-// 1 view 20.0, 2: 26.3, 4: 28.5, 8: 30.9, 16: 31.8 -- filling the chip matters more than keeping a
-// small group's state resident in the Infinity Cache, so the default is the whole batch (capped so
-// that the per-launch state stays in the low GB).
+// Views swept together by one launch (the views of a batch are independent, mvs_patchmatch.py:104-123, so
+// a batch can be swept in groups, each through the whole schedule).  Measured on MI355X, round 3 (16
+// views 1080p, k=7, S=4, G px-hyp/s, automatic strip height): groups of 16 / 8 / 4 / 2 views -> 41.6 /
+// 40.0 / 42.1 / 39.8 (rank shards of 8 views: 40.0 as one launch, 42.2 as two launches of 4): four
+// views fill two generations of resident waves exactly at 18-row strips, and an XCD's L2 then holds
+// the sources of 4 views instead of 16.  Hence groups of four when they divide the batch, else the whole
+// batch (capped so that the per-launch state stays in the low GB).
 int default_views_per_launch(const amvs_ctx *c, int n_ref)
 {
     (void)c;
+    if (n_ref >= 8 && n_ref % 4 == 0) return 4;
     return n_ref < 32 ? n_ref : 32;
 }
 

@@ -275,13 +275,16 @@ def main():
     refs = list(mine)
     srcs = [sources[r] for r in refs]
 
-    # N>1: the rank's views are swept in `nb` batches (two, even for a 4-view shard); the RCCL
+    # N>1: the rank's views are swept in `nb` batches (two from 8 views per rank on); the RCCL
     # all-gathers of batch b (three collectives: depth, normal, confidence -- 20 B/pixel, straight from
     # the sweep's output arrays) run on their own stream while the next batch / the next step is swept,
     # so K timed steps expose one batch's exchange once, before the closing barrier.  `first_step_ms` in
     # the output line is ONE step from an idle pipeline with its exchange fully inside: what a single
     # PatchMatchMVS.reconstruct pays (its last group's gather is exposed).
-    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 2) else 1)
+    # (two batches from 8 views per rank on -- the library sweeps a batch in groups of 4 views, its best
+    # launch shape, so batches of fewer than 4 views would cost more than their exposed exchange saves:
+    # measured on one GPU 39.8 against 42.1 G px-hyp/s)
+    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 8) else 1)
     nb = max(1, min(nb, n_loc))
     if args.gather_per_iteration:
         nb = 1                                  # a continuation call resumes the state of ONE batch
