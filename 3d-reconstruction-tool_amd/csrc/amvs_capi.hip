@@ -292,16 +292,20 @@ int resolve_fast(amvs_ctx *c, int requested, int *fast)
 }
 
 // Views swept together by one launch (the views of a batch are independent, mvs_patchmatch.py:104-123, so
-// a batch can be swept in groups, each through the whole schedule).  Measured on MI355X, round 3 (16
-// views 1080p, k=7, S=4, G px-hyp/s, automatic strip height): groups of 16 / 8 / 4 / 2 views -> 41.6 /
-// 40.0 / 42.1 / 39.8 (rank shards of 8 views: 40.0 as one launch, 42.2 as two launches of 4): four
-// views fill two generations of resident waves exactly at 18-row strips, and an XCD's L2 then holds
-// the sources of 4 views instead of 16.  Hence groups of four when they divide the batch, else the whole
-// batch (capped so that the per-launch state stays in the low GB).
-int default_views_per_launch(const amvs_ctx *c, int n_ref)
+// a batch can be swept in groups, each through the whole schedule).  Groups of FOUR views against the
+// whole 16-view batch, measured on MI355X in round 3 (S=4, G px-hyp/s, automatic strip heights, one run
+// per pair):
+//     fast, 1080p:  k=3  52.0 / 49.3    k=5  46.2 / 45.0    k=7  42.1 / 41.6    k=9  36.4 / 38.3    k=11  33.8 / 35.4
+//     fast, k=7:    2560x1440  36.4 / 38.8      3840x2160 (8 views: 4 / 8 per launch)  35.4 / 36.1
+//     exact, 1080p, k=7:  37.0 / 38.2           fast, 1080p, k=7, 8-view rank shard:  42.2 / 40.0
+// Four 1080p views are two generations of resident waves at 18-row strips and an XCD's L2 then serves the
+// sources of 4 views instead of 16 (hit rate 0.81 against 0.69); a launch of two generations also has a
+// relatively longer tail than one of six, which is what the wider images, the larger patches and the
+// slower exact kernel lose more to than the L2 returns.  Hence groups of four exactly where they were
+// measured to win, else the whole batch (capped so that the per-launch state stays in the low GB).
+int default_views_per_launch(const amvs_ctx *c, int n_ref, int patch, bool fast)
 {
-    (void)c;
-    if (n_ref >= 8 && n_ref % 4 == 0) return 4;
+    if (fast && patch <= 7 && c->W <= 2048 && n_ref >= 8 && n_ref % 4 == 0) return 4;
     return n_ref < 32 ? n_ref : 32;
 }
 
@@ -477,7 +481,7 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     const size_t hw = (size_t)c->H * c->W;
     // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
     // `vpl` views, each group through the whole schedule (see default_views_per_launch).
-    int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref);
+    int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref, p->patch_size, fast != 0);
     if (vpl > n_ref) vpl = n_ref;
     const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
     const int TH = p->tile_rows > 0 || !band_major

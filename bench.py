@@ -485,7 +485,7 @@ def main():
 
     n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
-    S = 4
+    S = len(srcs[0])                                 # 4 unless the scene has fewer than 5 views
     kname = ("pm_step_fast_kernel" if args.mode == "fast" else "pm_step_kernel") + f"<{args.patch},{S}>"
     bytes_per_hyp = 4 * S + 44                       # 60 B at S=4
     launch_ms = sweep_ms / max(launches, 1)

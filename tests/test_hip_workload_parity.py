@@ -159,7 +159,7 @@ def test_config5_64x4k_workload_fusion_on_device():
     proc = pm._prepare_images_device(sc.images(), ids, sc.poses)
     jobs = [(r, pm._select_source_views(r, ids, sc.poses, k=4)) for r in ids]
     res = pm._sweep_resident(torch, jobs, proc, sc.poses, ids)
-    assert pm._engine.last_views_per_launch() == 4                 # batches of 16 views, swept in groups of 4
+    assert pm._engine.last_views_per_launch() == 16                # 4K: the whole 16-view batch per launch
     pts, cols, raw = pm._fuse_filter_resident(res, proc, sc.poses)
     assert raw > 1000 and len(pts) > 1000, (raw, len(pts))
     host = res.to_host()

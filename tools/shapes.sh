@@ -1,7 +1,7 @@
 #!/bin/bash
 # other shapes in the fast arithmetic ("Other shapes")
 set -o pipefail
-O=gpurun_out/r2_shapes
+O=gpurun_out/${SHAPES_TAG:-r3_shapes}
 mkdir -p $O
 run() { tag=$1; shift
   timeout -k 10 500 python bench.py --no-planesweep --no-cpu-baseline "$@" > $O/$tag.json 2> $O/$tag.err || { echo "$tag failed"; tail -3 $O/$tag.err; return; }
