@@ -223,8 +223,12 @@ AMVS_DEV float xcost_t(const XArgs &a, JobCP job, const XRef<N> &R, int x, int y
                 const float rz = __builtin_amdgcn_rcpf(p2);
                 const float u = p0 * rz, v = p1 * rz;
                 const float x0f = __builtin_floorf(u), y0f = __builtin_floorf(v);
-                // (corner test + convexity: 0 <= x0f <= W-2; the clamp only guards rounding at the rim)
-                const int xi = min(max((int)x0f, 0), a.W - 2), yi = min(max((int)y0f, 0), a.H - 2);
+                // corner test + convexity: 0 <= x0f <= W-2 up to the rounding of the incremental chain, i.e.
+                // -1 .. W-1 at worst.  The packed maps carry a zero border of AMVS_PAIR_BORDER = 2 texels, so
+                // that range needs no clamp there (a footprint one texel outside reads zeros with a weight
+                // of ~1e-7); the float maps have no border and keep the clamp.
+                const int xi = U8 ? (int)x0f : min(max((int)x0f, 0), a.W - 2);
+                const int yi = U8 ? (int)y0f : min(max((int)y0f, 0), a.H - 2);
                 const float fx = u - x0f, fy = v - y0f;
                 float top, bot;
                 if constexpr (U8) {

@@ -83,6 +83,7 @@ class View:
         Rr, tr = self.poses[self.ref]
         self.Mb = [compose(self.K, Rr, tr, *self.poses[s]) for s in self.srcs]
         self.gray = self.codes[self.ref].astype(np.float32) / F(255.0)
+        self.padded = {v: np.pad(self.codes[v], 3) for v in set(self.srcs)}    # zero border (2 texels + the pair's +1)
         ys, xs = np.meshgrid(np.arange(self.H), np.arange(self.W), indexing="ij")
         self.xs, self.ys = xs.ravel(), ys.ravel()
 
@@ -130,7 +131,7 @@ class View:
         n_valid = np.zeros(P, np.int32)
         with np.errstate(all="ignore"):
             for s, (M, b) in zip(self.srcs, self.Mb):
-                img = self.codes[s]
+                img = self.padded[s]
                 Hm = [fma(b[r], (w0, w1, w2)[c], delta * M[3 * r + c]) for r in range(3) for c in range(3)]
                 ok = live.copy()
                 for c in range(4):
@@ -154,8 +155,10 @@ class View:
                         rz = F(1.0) / p2                       # (v_rcp_f32 on the device: 1 ulp)
                         u, v = p0 * rz, p1 * rz
                         x0f, y0f = np.floor(u), np.floor(v)
-                        xq = np.clip(np.nan_to_num(x0f, nan=0.0, posinf=0.0, neginf=0.0), 0, W - 2).astype(np.int64)
-                        yq = np.clip(np.nan_to_num(y0f, nan=0.0, posinf=0.0, neginf=0.0), 0, H - 2).astype(np.int64)
+                        # no clamp: the packed maps carry a zero border of 2 texels (pixels whose corner
+                        # tests failed are masked below; their indices are only kept inside the array)
+                        xq = np.clip(np.nan_to_num(x0f, nan=0.0, posinf=0.0, neginf=0.0), -2, W).astype(np.int64) + 3
+                        yq = np.clip(np.nan_to_num(y0f, nan=0.0, posinf=0.0, neginf=0.0), -2, H).astype(np.int64) + 3
                         fx, fy = u - x0f, v - y0f
                         t00 = img[yq, xq].astype(np.float32)
                         t10 = img[yq + 1, xq].astype(np.float32)
