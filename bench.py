@@ -14,8 +14,11 @@ resident in HBM.  Workload at N=1: BASELINE config 3 -- 16 views of 1920x1080, 7
 north_star's scaling target is 8 GPUs vs 1 on a 32-view scene): rank r sweeps its contiguous block
 of ceil(32/N) views (all images replicated on every GPU because source sets cross shard boundaries)
 and the per-view maps (depth, normal, confidence: 20 B/pixel) are all-gathered over RCCL inside the
-timed step (in two batches per step, the exchange of the first overlapping the sweep of the
-second) -- "scaling": "strong".  `--scaling weak` restores 16 views per GPU of a 16*N-view scene.
+timed step, on a second stream: the exchange of step k runs under the sweep of step k+1 (two buffer
+sets; from 8 views per rank on, a step is two batches and the first batch's exchange also overlaps the
+second batch's sweep) -- "scaling": "strong".  `first_step_ms` is ONE step from an idle pipeline with
+its exchange exposed (what a single reconstruct pays); `--gather-per-iteration` issues north_star's
+exchange after every iteration instead.  `--scaling weak` restores 16 views per GPU of a 16*N-view scene.
 
 `--mode fast` (default) times the tolerance arithmetic (AMVS_MODE_FAST), `--mode exact` the
 bit-exact one; both are parity-tested at this very size and launch shape
