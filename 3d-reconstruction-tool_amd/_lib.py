@@ -113,6 +113,10 @@ SIGNATURES = {
                                       C.c_float, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "amvs_set_view_colors": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint8)]),
     "amvs_fetch_cloud": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint8)]),
+    "amvs_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "amvs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    "amvs_allgather_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "amvs_comm_destroy": (C.c_int, [C.c_void_p]),
     "amvs_write_ply": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64]),
     "amvs_knn_mean_distance": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "amvs_selftest_lean_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -7,6 +7,9 @@
 #include "../../include/amvs.h"
 #include "amvs_kernels.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is resolved at run time (amvs_comm_*)
+
 #include <array>
 #include <cmath>
 #include <cstdio>
@@ -88,6 +91,9 @@ struct amvs_ctx {
     bool pm_resumable = false;
     int pm_cur = 0, pm_next_iteration = 0;
     uint64_t pm_key = 0;
+    // native exchange (amvs_comm_*): RCCL resolved with dlopen, one communicator per context
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
     // amvs_set_step_tuning: strip rows / resident workgroups per CU by [iteration][0 = propagation, 1 = refinement]
     // (0 = automatic); iterations beyond the table use its last row
     std::vector<int> tune_rows, tune_cap;
@@ -780,6 +786,7 @@ int amvs_destroy(amvs_ctx *c)
     if (!c) return AMVS_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)amvs_comm_destroy(c);
     for (int i = 0; i < 2; ++i) {
         if (c->d_depth[i]) (void)hipFree(c->d_depth[i]);
         if (c->d_cost[i]) (void)hipFree(c->d_cost[i]);
@@ -1773,6 +1780,101 @@ int amvs_knn_mean_distance(amvs_ctx *c, const double *points, int64_t n, int k, 
     int rc = bind_device(c);
     if (rc) return rc;
     HIPCHK(c, amvs::knn_mean_distance(points, (long long)n, k, mean_out, c->stream));
+    return AMVS_OK;
+}
+
+// ---- native exchange: RCCL through dlopen (no link-time dependency; with a PyTorch-ROCm wheel in the
+// process the SONAME librccl.so.1 resolves to the copy torch already loaded) ----
+extern "C++" {
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl q;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            q.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (q.lib) break;
+        }
+        if (!q.lib) { q.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return q; }
+        q.GetUniqueId = (decltype(q.GetUniqueId))dlsym(q.lib, "ncclGetUniqueId");
+        q.CommInitRank = (decltype(q.CommInitRank))dlsym(q.lib, "ncclCommInitRank");
+        q.AllGather = (decltype(q.AllGather))dlsym(q.lib, "ncclAllGather");
+        q.CommDestroy = (decltype(q.CommDestroy))dlsym(q.lib, "ncclCommDestroy");
+        q.GetErrorString = (decltype(q.GetErrorString))dlsym(q.lib, "ncclGetErrorString");
+        if (!q.GetUniqueId || !q.CommInitRank || !q.AllGather || !q.CommDestroy || !q.GetErrorString)
+            q.why = "RCCL library lacks an expected symbol";
+        return q;
+    }();
+    return r;
+}
+
+int rccl_fail(amvs_ctx *c, const char *what, ncclResult_t e)
+{
+    return fail(c, AMVS_EHIP, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error"));
+}
+}  // namespace
+}  // extern "C++"
+
+int amvs_comm_unique_id(uint8_t id_out[AMVS_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == AMVS_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return fail(nullptr, AMVS_EINVAL, "NULL id");
+    if (!rccl().why.empty()) return fail(nullptr, AMVS_EUNSUPPORTED, rccl().why);
+    ncclUniqueId id;
+    const ncclResult_t e = rccl().GetUniqueId(&id);
+    if (e != ncclSuccess) return rccl_fail(nullptr, "ncclGetUniqueId", e);
+    std::memcpy(id_out, &id, AMVS_COMM_ID_BYTES);
+    return AMVS_OK;
+}
+
+int amvs_comm_init(amvs_ctx *c, int rank, int world, const uint8_t id_in[AMVS_COMM_ID_BYTES])
+{
+    if (!c) return AMVS_EINVAL;
+    if (!id_in || world < 1 || rank < 0 || rank >= world) return fail(c, AMVS_EINVAL, "bad rank / world / id");
+    if (!rccl().why.empty()) return fail(c, AMVS_EUNSUPPORTED, rccl().why);
+    int rc = bind_device(c);
+    if (rc) return rc;
+    if ((rc = amvs_comm_destroy(c))) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, AMVS_COMM_ID_BYTES);
+    const ncclResult_t e = rccl().CommInitRank(&c->comm, world, id, rank);
+    if (e != ncclSuccess) { c->comm = nullptr; return rccl_fail(c, "ncclCommInitRank", e); }
+    c->comm_rank = rank; c->comm_world = world;
+    return AMVS_OK;
+}
+
+int amvs_allgather_maps(amvs_ctx *c, const void *local_dev, void *full_dev, int64_t floats_per_rank)
+{
+    if (!c) return AMVS_EINVAL;
+    if (!c->comm) return fail(c, AMVS_EINVAL, "no communicator (amvs_comm_init)");
+    if (!local_dev || !full_dev || floats_per_rank < 1) return fail(c, AMVS_EINVAL, "bad buffers / count");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    const ncclResult_t e = rccl().AllGather(local_dev, full_dev, (size_t)floats_per_rank, ncclFloat, c->comm, c->stream);
+    if (e != ncclSuccess) return rccl_fail(c, "ncclAllGather", e);
+    return AMVS_OK;
+}
+
+int amvs_comm_destroy(amvs_ctx *c)
+{
+    if (!c) return AMVS_EINVAL;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        const ncclResult_t e = rccl().CommDestroy(c->comm);
+        c->comm = nullptr; c->comm_world = 0;
+        if (e != ncclSuccess) return rccl_fail(c, "ncclCommDestroy", e);
+    }
     return AMVS_OK;
 }
 

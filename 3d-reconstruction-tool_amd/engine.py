@@ -112,6 +112,28 @@ class Engine:
         self._chk(self._lib.amvs_get_step_times(self._h, _p(out), out.size, C.byref(n)))
         return out[: n.value]
 
+    # -- native exchange (RCCL behind the C ABI; the classes use torch.distributed) ------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 creates it, the caller hands it to the other ranks)."""
+        lib = _lib.load()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.amvs_comm_unique_id(buf)
+        if rc != 0:
+            raise AmvsError(f"amvs_comm_unique_id failed ({rc}): {lib.amvs_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self._lib.amvs_comm_init(self._h, int(rank), int(world), buf))
+
+    def allgather_maps(self, local_ptr, full_ptr, floats_per_rank):
+        """ncclAllGather of floats_per_rank float32 per rank, device pointers, on the engine's stream."""
+        self._chk(self._lib.amvs_allgather_maps(self._h, C.c_void_p(local_ptr), C.c_void_p(full_ptr), int(floats_per_rank)))
+
+    def comm_destroy(self):
+        self._chk(self._lib.amvs_comm_destroy(self._h))
+
     # -- lifecycle ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):

@@ -340,6 +340,26 @@ int amvs_box_stats(amvs_ctx *ctx, int view, int patch_size, float *mean_out, flo
 int amvs_rng_fill(amvs_ctx *ctx, uint64_t seed, uint32_t stream_view, uint32_t draw,
                   int64_t n, float *u_out, float *n_out);
 
+/* ---- native exchange between ranks (amvs_comm_init / amvs_allgather_maps) ----
+ * For a consumer of this ABI WITHOUT torch.distributed (the Python classes use torch's process group,
+ * which issues the same RCCL calls).  One process per GPU; the reference has no counterpart (its loop
+ * over views is serial, mvs_patchmatch.py:104-123).  RCCL is resolved at run time (dlopen of
+ * librccl.so.1 -- the copy already in the process when a PyTorch-ROCm wheel loaded one, the system copy
+ * otherwise), so libamvs.so carries no link-time dependency on it.
+ *   amvs_comm_unique_id   rank 0 creates the 128-byte id; the caller sends it to the other ranks
+ *                         (any transport: a file, MPI, a socket) -- ncclGetUniqueId
+ *   amvs_comm_init        every rank, with the same id: ncclCommInitRank on the context's device
+ *   amvs_allgather_maps   all-gather of `floats_per_rank` float32 from local_dev into full_dev
+ *                         ([world][floats_per_rank], rank order), device pointers, enqueued on the
+ *                         context's stream behind the sweep that produced local_dev -- ncclAllGather;
+ *                         full_dev + rank * floats_per_rank may be local_dev itself (in place)
+ *   amvs_comm_destroy     ncclCommDestroy (also done by amvs_destroy)                                 */
+#define AMVS_COMM_ID_BYTES 128
+int amvs_comm_unique_id(uint8_t id_out[AMVS_COMM_ID_BYTES]);
+int amvs_comm_init(amvs_ctx *ctx, int rank, int world, const uint8_t id[AMVS_COMM_ID_BYTES]);
+int amvs_allgather_maps(amvs_ctx *ctx, const void *local_dev, void *full_dev, int64_t floats_per_rank);
+int amvs_comm_destroy(amvs_ctx *ctx);
+
 /* utils.save_ply (utils.py:8-37): ASCII PLY with "%.6f %.6f %.6f %d %d %d" per vertex; the same
  * bytes as the reference writes, through one buffered native writer (no GPU involved; ctx-free).
  * points: n x 3 float64, colors: n x 3 int64 (the reference casts with .astype(int)).          */

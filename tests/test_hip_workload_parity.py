@@ -250,3 +250,36 @@ def test_sweep_continued_one_iteration_per_call(scene_a, mode, entry):
             run(eng, n=1, first_iteration=1)                     # 3 iterations were run, not 1
         with pytest.raises(amvs.AmvsError):
             eng.patchmatch([2], [[1, 3, 0, 4]], make_pm_params(7, 1, samples, sc.depth_min, sc.depth_max, first_iteration=3), 9)
+
+
+def test_native_rccl_entry_points_single_rank():
+    """amvs_comm_unique_id / amvs_comm_init / amvs_allgather_maps / amvs_comm_destroy (include/amvs.h): the
+    native exchange of a C-ABI consumer without torch.distributed, RCCL resolved with dlopen.  One GPU
+    here, so a one-rank communicator: the all-gather, enqueued on the engine's stream behind a sweep,
+    must deliver this rank's maps -- out of place and in place.  (Two ranks need two GPUs.)"""
+    import torch
+
+    import amvs
+    from amvs.engine import make_pm_params
+    from conftest import GoldenScene
+    sc = GoldenScene("scene_a")
+    dev = torch.device("cuda", 0)
+    hw = sc.H * sc.W
+    with sc.engine("fast") as eng:
+        eng.comm_init(0, 1, amvs.Engine.comm_unique_id())
+        d = torch.zeros((1, hw), dtype=torch.float32, device=dev)
+        n = torch.zeros((1, 3 * hw), dtype=torch.float32, device=dev)
+        c = torch.zeros((1, hw), dtype=torch.float32, device=dev)
+        full = torch.full((1, hw), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max)
+        eng.patchmatch_device([2], [[1, 3, 0, 4]], p, 5, d.data_ptr(), n.data_ptr(), c.data_ptr())
+        eng.allgather_maps(d.data_ptr(), full.data_ptr(), hw)          # stream-ordered behind the sweep
+        eng.allgather_maps(n.data_ptr(), n.data_ptr(), 3 * hw)         # in place
+        eng.sync()
+        assert torch.equal(full, d) and float(d.min()) >= sc.depth_min - 1e-6
+        want = eng.patchmatch([2], [[1, 3, 0, 4]], p, 5)
+        assert np.array_equal(n.cpu().numpy().reshape(sc.H, sc.W, 3), want[1][0])
+        eng.comm_destroy()
+        with pytest.raises(amvs.AmvsError):
+            eng.allgather_maps(d.data_ptr(), full.data_ptr(), hw)      # no communicator any more
