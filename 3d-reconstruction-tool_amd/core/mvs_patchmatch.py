@@ -379,7 +379,9 @@ class PatchMatchMVS:
         hw = H * W
         dev = torch.device("cuda", self.device_id)
         n = len(jobs)
-        if world == 1:
+        # (exercise_exchange: run the multi-rank code path -- row groups, second stream, collectives --
+        # on a one-rank process group as well; how the RCCL calls are rehearsed on a one-GPU box)
+        if world == 1 and not (getattr(self, "exercise_exchange", False) and torch.distributed.is_initialized()):
             depth = torch.empty((n, hw), dtype=torch.float32, device=dev)
             normal = torch.empty((n, 3 * hw), dtype=torch.float32, device=dev)
             conf = torch.empty((n, hw), dtype=torch.float32, device=dev)

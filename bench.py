@@ -224,7 +224,15 @@ def main():
     backend = os.environ.get("AMVS_BENCH_BACKEND", "nccl")
     if os.environ.get("AMVS_BENCH_ONE_DEVICE") == "1":
         local = 0
-    if args.gpus > 1 or world > 1:
+    # AMVS_BENCH_FORCE_EXCHANGE=1: run the N>1 code path (two buffer sets, comm stream, collectives, events)
+    # on a ONE-rank process group -- how the RCCL calls are rehearsed on a one-GPU box
+    force = os.environ.get("AMVS_BENCH_FORCE_EXCHANGE") == "1"
+    if force:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if args.gpus > 1 or world > 1 or force:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -240,7 +248,8 @@ def main():
     from amvs.synthetic import make_scene
 
     H, W = args.height, args.width
-    strong = world > 1 and args.scaling == "strong"
+    multi = world > 1 or force                       # the exchange is part of the step
+    strong = multi and args.scaling == "strong"
     n_views = args.scene_views if strong else args.views_per_gpu * world
     vpg = -(-n_views // world)                      # views per GPU (ceil)
     # synthetic calibrated scene rendered on the GPU (data generation, outside the timed region)
@@ -267,11 +276,11 @@ def main():
                             args.views_per_launch, schedule=args.schedule)
     eng.set_split_tuning(args.split_groups, args.split_rows, args.split_lds)
     n_loc = len(mine)
-    if world > 1:
+    if multi:
         assert n_views % world == 0, "the bench shards equal blocks: --scene-views must be a multiple of --gpus"
     # N>1: two sets of output maps used alternately, so that the all-gather of step k (which reads the
     # maps in place, no packed copy) can run under the sweep of step k+1
-    nbuf = 2 if world > 1 else 1
+    nbuf = 2 if multi else 1
     depth = torch.empty((nbuf, n_loc, H, W), dtype=torch.float32, device=dev)
     normal = torch.empty((nbuf, n_loc, H, W, 3), dtype=torch.float32, device=dev)
     conf = torch.empty((nbuf, n_loc, H, W), dtype=torch.float32, device=dev)
@@ -287,7 +296,7 @@ def main():
     # (two batches from 8 views per rank on -- the library sweeps a batch in groups of 4 views, its best
     # launch shape, so batches of fewer than 4 views would cost more than their exposed exchange saves:
     # measured on one GPU 39.8 against 42.1 G px-hyp/s)
-    nb = args.batches if args.batches > 0 else (2 if (world > 1 and n_loc >= 8) else 1)
+    nb = args.batches if args.batches > 0 else (2 if (multi and n_loc >= 8) else 1)
     nb = max(1, min(nb, n_loc))
     if args.gather_per_iteration:
         nb = 1                                  # a continuation call resumes the state of ONE batch
@@ -297,12 +306,12 @@ def main():
     full = [dict(d=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev),
                  n=torch.empty((world, n_loc, 3 * H * W), dtype=torch.float32, device=gdev),
                  c=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev)) for _ in range(nbuf)] \
-        if world > 1 else None
+        if multi else None
     fusion_inputs = None
     if args.fusion:
         # config 5: the fused, filtered cloud is part of the step (on rank 0, which like every rank
         # holds all maps after the gather)
-        fusion_inputs = (None if backend != "gloo" or world == 1 else np.stack([sc.colors[r] for r in ids]),
+        fusion_inputs = (None if backend != "gloo" or not multi else np.stack([sc.colors[r] for r in ids]),
                          np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in ids])
     in_flight = []
     state = {"step": 0, "cloud": None, "fusion_s": 0.0}
@@ -319,7 +328,7 @@ def main():
     def fuse(k):
         t_f = time.perf_counter()
         cols, K_inv, pose_list = fusion_inputs
-        if world == 1:
+        if not multi:
             torch.cuda.synchronize()
             out = eng.fuse_filter_views(ids, depth[k].data_ptr(), conf[k].data_ptr(), K_inv, pose_list, 3, True)
         elif backend == "nccl":
@@ -335,13 +344,13 @@ def main():
         k = state["step"] % nbuf
         state["step"] += 1
         works = []
-        if world > 1 and gathered[k] is not None:
+        if multi and gathered[k] is not None:
             stream.wait_event(gathered[k])
         for b in range(nb):
             lo, hi = bounds[b], bounds[b + 1]
             eng.patchmatch_device(refs[lo:hi], srcs[lo:hi], params, 42, depth[k, lo:hi].data_ptr(),
                                   normal[k, lo:hi].data_ptr(), conf[k, lo:hi].data_ptr())
-            if world > 1:
+            if multi:
                 done = torch.cuda.Event()
                 done.record(stream)
                 with torch.cuda.stream(comm_stream):
@@ -366,7 +375,7 @@ def main():
                     ev.record(comm_stream)
                     gathered[k] = ev
         eng.sync()
-        if world > 1:
+        if multi:
             in_flight.append(works)
             # the buffers of this step are rewritten two steps from now: the step before this one must
             # be through; with the fusion inside the step, this step's own exchange as well
@@ -384,7 +393,7 @@ def main():
         it_n = torch.empty((2, n_loc, 3 * H * W), dtype=torch.float32, device=dev)
         it_full = [dict(d=torch.empty((world * n_loc, H * W), dtype=torch.float32, device=gdev),
                         n=torch.empty((world * n_loc, 3 * H * W), dtype=torch.float32, device=gdev)) for _ in range(2)] \
-            if world > 1 else None
+            if multi else None
         it_gathered = [None, None]
         state["it_gathers"] = 0
 
@@ -392,7 +401,7 @@ def main():
         k = state["step"] % nbuf
         state["step"] += 1
         works = []
-        if world > 1 and gathered[k] is not None:
+        if multi and gathered[k] is not None:
             stream.wait_event(gathered[k])
         for it in range(args.iters):
             last = it == args.iters - 1
@@ -401,7 +410,7 @@ def main():
                 stream.wait_event(it_gathered[j])         # the exchange that read this set two iterations ago
             outs = (depth[k], normal[k], conf[k]) if last else (it_d[j], it_n[j], conf[k])
             eng.patchmatch_device(refs, srcs, it_params[it], 42, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
-            if world == 1:
+            if not multi:
                 continue
             done = torch.cuda.Event()
             done.record(stream)
@@ -431,7 +440,7 @@ def main():
                     state["it_gathers"] += 1
                 works += mine_works
         eng.sync()
-        if world > 1:
+        if multi:
             in_flight.append(works)
             drain(keep_last_step=not args.fusion)
         if args.fusion and rank == 0:
@@ -442,10 +451,10 @@ def main():
 
     def fence():
         drain(keep_last_step=False)
-        if world > 1:
+        if multi:
             comm_stream.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -473,7 +482,7 @@ def main():
     fence()
     first_step = time.perf_counter() - t1
     k_last = (state["step"] - 1) % nbuf
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed, first_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, first_step = float(tt[0].item()), float(tt[1].item())
@@ -541,7 +550,7 @@ def main():
             out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": True,
                                    "points_per_s": round(len(pts) / (elapsed / args.steps), 1),
                                    "device_fusion_s": round(state["fusion_s"] / args.steps, 4)}
-        elif world == 1:
+        elif not multi:
             torch.cuda.synchronize()
             t_f = time.perf_counter()
             pts, cols, raw = eng.fuse_filter_views(refs, depth[k_last].data_ptr(), conf[k_last].data_ptr(),
@@ -565,7 +574,7 @@ def main():
             torch.cuda.empty_cache()
             out["planesweep"] = run_planesweep(args, steps=5, warmup=1, with_cpu=not args.no_cpu_baseline, cpu_reps=3)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -160,6 +160,57 @@ def test_reconstruct_two_ranks_rccl_matches_single_process(scene_a):
         assert np.array_equal(cols, single_cols)
 
 
+def _rccl_one_rank_worker(port, q, mode):
+    """A ONE-rank nccl (= RCCL) process group on cuda:0 with the multi-rank code path forced on: the
+    row groups, the second stream, the event ordering and the RCCL all-gather calls of _sweep_resident
+    execute for real (with a single peer); the stereo path's device gather likewise."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import GoldenScene
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import amvs
+        from amvs.core.mvs_patchmatch import PatchMatchMVS
+        scene = GoldenScene("scene_a")
+        pm = PatchMatchMVS(amvs.Camera(K=scene.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7, num_iterations=2,
+                           num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0, mode=mode, device_prep=True)
+        pm.exercise_exchange = True
+        pm._estimate_depth_range = lambda poses, sparse: None
+        pm.depth_min, pm.depth_max = scene.depth_min, scene.depth_max
+        q.put(pm.reconstruct([{"image": c} for c in scene.colors], scene.poses()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_reconstruct_rccl_code_path_on_a_one_rank_group(scene_a):
+    """The nccl branches of _sweep_resident (direct device all-gathers, group by group, on the comm
+    stream) executed on real RCCL -- with the only topology a one-GPU box offers, a one-rank group --
+    return the cloud of the plain single-process run."""
+    import amvs
+    import torch.multiprocessing as mp
+    from amvs.core.mvs_patchmatch import PatchMatchMVS
+    pm = PatchMatchMVS(amvs.Camera(K=scene_a.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7, num_iterations=2,
+                       num_samples=2, min_views=2, seed=5, views_per_batch=2, device=0, mode="fast", device_prep=True)
+    pm._estimate_depth_range = lambda poses, sparse: None
+    pm.depth_min, pm.depth_max = scene_a.depth_min, scene_a.depth_max
+    want_p, want_c = pm.reconstruct([{"image": c} for c in scene_a.colors], scene_a.poses())
+    assert len(want_p) > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q, "fast"))
+    p.start()
+    pts, cols = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert np.array_equal(pts, want_p) and np.array_equal(cols, want_c)
+
+
 def _stereo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)

@@ -7,3 +7,8 @@ for extra in "" "--gather-per-iteration"; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 \
     bench.py --gpus 2 --steps 2 --warmup 1 --scene-views ${VIEWS:-8} --no-planesweep $extra 2>&1 | grep -v "amdgpu.ids\|OMP_NUM\|^\*\*\*" || exit 1
 done
+# the same two exchanges on real RCCL with the only topology a one-GPU box offers: a ONE-rank nccl group
+unset AMVS_BENCH_BACKEND AMVS_BENCH_ONE_DEVICE
+for extra in "" "--gather-per-iteration"; do
+  AMVS_BENCH_FORCE_EXCHANGE=1 python bench.py --gpus 1 --steps 2 --warmup 1 --scene-views 16 --no-planesweep --no-cpu-baseline $extra 2>&1 | grep -v "amdgpu.ids" || exit 1
+done
