@@ -560,6 +560,23 @@ def main():
             out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": False,
                                    "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),
                                    "device_fusion_s": round(t_f, 4)}
+        elif multi:
+            # several ranks: every rank holds all maps after the exchange; rank 0 fuses the gathered maps of
+            # the last step (untimed above, like the one-GPU line) -- "dense points/s at 1/2/4/8 GPU"
+            torch.cuda.synchronize()
+            t_f = time.perf_counter()
+            K_inv, pose_list = np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in ids]
+            if backend == "nccl":
+                pts, cols, raw = eng.fuse_filter_views(ids, full[k_last]["d"].data_ptr(), full[k_last]["c"].data_ptr(),
+                                                       K_inv, pose_list, 3, True)
+            else:
+                pts, cols, raw = eng.fuse_filter(full[k_last]["d"].numpy().reshape(n_views, H, W),
+                                                 full[k_last]["c"].numpy().reshape(n_views, H, W),
+                                                 np.stack([sc.colors[r] for r in ids]), K_inv, pose_list, 3, True)
+            t_f = time.perf_counter() - t_f
+            out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": False,
+                                   "points_per_s": round(len(pts) / (elapsed / args.steps + t_f), 1),
+                                   "device_fusion_s": round(t_f, 4)}
         if world == 1 and not args.no_cpu_baseline:
             sample_refs = [n_views // 2, n_views // 2 + 1][: max(1, min(2, n_views))]
             out["cpu_baseline"] = cpu_baseline(sc, args.patch, sources, sample_refs, sc.depth_min, sc.depth_max,
