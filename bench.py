@@ -201,6 +201,9 @@ def main():
                          "(amvs_pm_params.first_iteration) and the ranks all-gather the depth / normal maps after EVERY "
                          "iteration (the gather of iteration i under the sweep of iteration i+1; the maps do not feed "
                          "back -- the reference has no view propagation -- so the results are those of the default run)")
+    ap.add_argument("--as-rank-of", type=int, default=0,
+                    help="one GPU, no exchange: sweep only the shard rank 0 of an N-rank run would sweep (of the "
+                         "--scene-views scene): the per-rank sweep time of an N-GPU run measured on one GPU")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5 preset: 64 views of 3840x2160 over the ranks, fusion inside the step")
     args = ap.parse_args()
@@ -250,14 +253,14 @@ def main():
     H, W = args.height, args.width
     multi = world > 1 or force                       # the exchange is part of the step
     strong = multi and args.scaling == "strong"
-    n_views = args.scene_views if strong else args.views_per_gpu * world
+    n_views = args.scene_views if (strong or args.as_rank_of > 0) else args.views_per_gpu * world
     vpg = -(-n_views // world)                      # views per GPU (ceil)
     # synthetic calibrated scene rendered on the GPU (data generation, outside the timed region)
     sc = make_scene(n_views, H, W, seed=1234, device=str(dev))
     ids = sorted(sc.poses)
     pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
     sources = {r: pm._select_source_views(r, ids, sc.poses, k=4) for r in ids}
-    mine = shard(n_views, rank, world)
+    mine = shard(n_views, rank, world) if args.as_rank_of <= 0 else shard(n_views, 0, args.as_rank_of)
 
     eng = amvs.Engine(H, W, n_views, sc.camera.K.astype(np.float32), device=local, mode=args.mode)
     stream = torch.cuda.Stream(device=dev)
@@ -495,7 +498,7 @@ def main():
         assert float(other.min()) >= float(np.float32(sc.depth_min)) - 1e-3, "all-gather: peer rows empty"
         assert float(full[k_last]["n"][(rank + 1) % world].abs().max()) > 0.0, "all-gather: peer normals empty"
 
-    n_hyp_step = n_views * H * W * args.iters * (2 + args.samples)
+    n_hyp_step = (n_views if args.as_rank_of <= 0 else len(mine)) * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
     S = len(srcs[0])                                 # 4 unless the scene has fewer than 5 views
     kname = ("pm_step_fast_kernel" if args.mode == "fast" else "pm_step_kernel") + f"<{args.patch},{S}>"
