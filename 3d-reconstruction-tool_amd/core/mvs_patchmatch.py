@@ -368,8 +368,9 @@ class PatchMatchMVS:
         the launches are capped at a group, and as soon as the launches covering a group are enqueued its
         all-gather (RCCL: three collectives -- depth, confidence, normals -- on a second stream, ordered
         after the sweep by an event) runs under the sweep of the next group.  Only the last group's
-        exchange is exposed.  No host synchronisation happens between the first launch and the last
-        collective; the progress lines are printed afterwards.  The reference loops serially and has no
+        exchange is exposed.  The host never waits for a collective before the last launch is enqueued (a
+        call only waits for the sweep stream while it stages its job table); the progress lines are
+        printed afterwards.  The reference loops serially and has no
         exchange (:104-123)."""
         n_cams = len(cam_indices)
         rank, world = _parallel.rank_world(self.process_group)
