@@ -237,3 +237,58 @@ def test_save_ply_writes_the_reference_bytes(tmp_path):
     assert out.read_text() == "\n".join(want) + "\n"
     save_ply(np.zeros((0, 3)), np.zeros((0, 3)), str(tmp_path / "empty.ply"))
     assert (tmp_path / "empty.ply").read_text().count("\n") == 10
+
+
+def test_bench_labels_and_evidence_helpers():
+    """bench.py's host-side helpers: a BASELINE config is named only when the run IS that config; the
+    traffic figure is served only for the exact workload key and the kernel sources it was measured on."""
+    import argparse
+    import bench
+    a = argparse.Namespace(patch=7, iters=8, samples=8, fusion=False)
+    assert bench.baseline_label(a, 16, 1920, 1080, 1).startswith("BASELINE config 3")
+    assert bench.baseline_label(a, 32, 1920, 1080, 4).startswith("BASELINE config 4")
+    assert bench.baseline_label(a, 8, 1920, 1080, 2).startswith("custom workload")          # the 8-view rehearsal scene
+    assert bench.baseline_label(a, 16, 1280, 720, 1).startswith("custom workload")
+    a.fusion = True
+    assert bench.baseline_label(a, 64, 3840, 2160, 8).startswith("BASELINE config 5")
+    a.fusion, a.patch = False, 11
+    assert bench.baseline_label(a, 16, 1920, 1080, 1).startswith("custom workload")
+    h = bench.kernel_source_hash("pm_step_fast_kernel<7,4>")
+    assert len(h) == 40 and h != bench.kernel_source_hash("pm_step_kernel<7,4>")
+    assert bench.profiled_traffic("pm_step_fast_kernel<7,4>", "no such workload") is None
+    assert bench.profiled_traffic("no such kernel<1,1>", "4x1920x1080") is None
+    t = bench.profiled_traffic("pm_step_fast_kernel<7,4>", "4x1920x1080")
+    assert t is None or t > 0                      # None as soon as the kernel sources differ from the profiled ones
+    r = bench.valu_issue_roofline("plane_sweep_fast_kernel<5,6>", "8x1280x720", 6.6e8, 6.7)
+    assert r is None or (r["bound"] == "valu-issue" and 0.3 < r["frac"] < 1.2)
+
+
+def test_extended_restatement_is_sane_on_the_cpu():
+    """oracle/xpm_oracle.py on its own (no GPU): at the true depth with fronto-parallel planes the window
+    cost is low, at a wrong depth high; the view candidates land near the true depth; a half sweep from a
+    perturbed map moves its colour towards the truth and leaves the other colour alone."""
+    from oracle import oracle, xpm_oracle
+    from amvs.synthetic import make_scene
+    sc = make_scene(5, 48, 64, seed=17)
+    codes = [np.round(g * 255).clip(0, 255).astype(np.uint8) for g in sc.grays]
+    K = sc.camera.K.astype(np.float32)
+    poses = [(sc.poses[i].R, sc.poses[i].t) for i in range(5)]
+    v = xpm_oracle.View(K, np.linalg.inv(K), codes, poses, 2, [1, 3, 0, 4], 7, 2)
+    n = np.zeros((48, 64, 3), np.float32)
+    n[..., 2] = -1
+    gt = sc.depths[2].astype(np.float32)
+    c_gt, c_bad = v.cost_map(gt, n), v.cost_map(gt * np.float32(1.2), n)
+    fin = np.isfinite(c_gt) & np.isfinite(c_bad)
+    assert fin.mean() > 0.5 and np.median(c_gt[fin]) < 0.25 < np.median(c_bad[fin])
+    d_all = np.stack([sc.depths[i].astype(np.float32) for i in range(5)])
+    cd, cn = v.view_candidates(d_all, np.stack([n] * 5), 0, sc.depth_min, sc.depth_max)
+    m = cd > 0
+    assert m.mean() > 0.8 and np.median(np.abs(cd[m] - gt[m]) / gt[m]) < 5e-3
+    start = gt * np.float32(1.05)
+    D, N, C = v.half_sweep(start, n, np.full((48, 64), np.inf, np.float32), cd, cn, 0, 0, 11, oracle.rng_fill,
+                           sc.depth_min, sc.depth_max)
+    yy, xx = np.mgrid[0:48, 0:64]
+    swept = ((xx + yy) & 1) == 0
+    assert np.array_equal(D[~swept], start[~swept]) and np.isinf(C[~swept]).all()
+    got = swept & np.isfinite(C)
+    assert got.mean() > 0.25 and np.median(np.abs(D[got] - gt[got]) / gt[got]) < 0.01
