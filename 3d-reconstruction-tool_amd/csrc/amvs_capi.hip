@@ -690,6 +690,7 @@ int one_step_begin(amvs_ctx *c, int ref, const int *src_ids, int n_src, int patc
     int fast = 0;
     if ((rc = resolve_fast(c, AMVS_MODE_DEFAULT, &fast))) return rc;
     if ((rc = upload_jobs(c, 1, &ref, src_ids, n_src, fast ? patch : 0))) return rc;
+    c->pm_resumable = false;                    // the single-step entry points overwrite the state of slot 0
     o.c = c; o.patch = patch; o.n_src = n_src; o.hw = (size_t)c->H * c->W;
     o.a = base_args(c, patch, 1, pick_tile_rows(c, patch, n_src, 1, 0, 64, fast != 0));
     o.a.fast = fast;
@@ -844,6 +845,7 @@ int amvs_sync(amvs_ctx *c)
 static int set_view_common(amvs_ctx *c, int view, const void *gray, const float R[9], const float t[3],
                            hipMemcpyKind kind)
 {
+    if (c) c->pm_resumable = false;             // new images / poses: a sweep cannot be continued across them
     if (!c) return AMVS_EINVAL;
     if (view < 0 || view >= c->n_views || !gray || !R || !t) return fail(c, AMVS_EINVAL, "bad view argument");
     int rc = bind_device(c);
@@ -890,6 +892,7 @@ static void resize_axis_tables(int n_dst, int n_src, std::vector<int> &ofs, std:
 int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h, int src_w, const float R[9],
                        const float t[3], uint8_t *scaled_bgr_out)
 {
+    if (c) c->pm_resumable = false;
     if (!c) return AMVS_EINVAL;
     if (view < 0 || view >= c->n_views || !bgr_host || !R || !t || src_h < 1 || src_w < 1)
         return fail(c, AMVS_EINVAL, "bad view argument");
@@ -1649,6 +1652,7 @@ int amvs_init_state(amvs_ctx *c, uint64_t seed, uint32_t stream_view, float log_
     if (!depth || !normal || !cost) return fail(c, AMVS_EINVAL, "NULL argument");
     int rc = bind_device(c);
     if (rc) return rc;
+    c->pm_resumable = false;
     if ((rc = ensure_slots(c, 1))) return rc;
     if ((rc = ensure_jobs(c, 1))) return rc;
     amvs::Job j;
