@@ -358,6 +358,34 @@ class PatchMatchMVS:
             runs.append(cur)
         return runs
 
+    def _plan_group_launches(self, jobs, mine, per, base, views_per_batch):
+        """The launch / exchange plan of one rank in the several-rank _sweep_resident: its block of `per`
+        rows (row = job - base) is cut into row groups that are THE SAME ON EVERY RANK, its jobs into
+        launches (consecutive jobs, one source count, at most a group long, never straddling a group
+        boundary).  Returns (groups, plan): groups = [(first row, end row)], plan = [(jobs of a launch or
+        None, [indices of the groups to all-gather right after it])] -- every group exactly once, in
+        order, on every rank (also on a rank without views: the collectives must match)."""
+        n_groups = 2 if per >= 2 else 1
+        group_rows = (per + n_groups - 1) // n_groups
+        groups = [(g * group_rows, min((g + 1) * group_rows, per)) for g in range(n_groups)]
+        plan, next_group = [], 0
+        for chunk in self._batches_in_row_order(jobs, mine, min(views_per_batch, group_rows)):
+            lo = 0
+            while lo < len(chunk):
+                row = chunk[lo] - base
+                room = groups[min(row // group_rows, n_groups - 1)][1] - row
+                piece = chunk[lo:lo + room]
+                lo += room
+                done_rows = piece[-1] - base + 1
+                ready = []
+                while next_group < n_groups and (done_rows >= groups[next_group][1] or done_rows == len(mine)):
+                    ready.append(next_group)
+                    next_group += 1
+                plan.append((piece, ready))
+        if next_group < n_groups:
+            plan.append((None, list(range(next_group, n_groups))))
+        return groups, plan
+
     def _sweep_resident(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
         """_sweep with the maps kept in device tensors: this rank's views are swept straight into
         its block of rows (amvs_patchmatch_device) and the valid-pixel counts of the progress lines are
@@ -409,9 +437,7 @@ class PatchMatchMVS:
         direct = dist.get_backend(self.process_group) == "nccl"
         per = (n + world - 1) // world                    # rows per rank block (the last block may be short)
         base = rank * per
-        n_groups = 2 if per >= 2 else 1
-        group_rows = (per + n_groups - 1) // n_groups
-        groups = [(g * group_rows, min((g + 1) * group_rows, per)) for g in range(n_groups)]
+        groups, plan = self._plan_group_launches(jobs, mine, per, base, self.views_per_batch)
         # job j lives in row j (blocks are contiguous in job order); rows >= n are padding
         depth = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
         normal = torch.zeros((world * per, 3 * hw), dtype=torch.float32, device=dev)
@@ -442,32 +468,17 @@ class PatchMatchMVS:
 
         t1 = time.time()
         try:
-            done_rows, next_group = 0, 0
-            for chunk in self._batches_in_row_order(jobs, mine, min(self.views_per_batch, group_rows)):
-                # a launch never straddles a group boundary: cut it there
-                pieces, lo = [], 0
-                while lo < len(chunk):
-                    row = chunk[lo] - base
-                    room = groups[min(row // group_rows, n_groups - 1)][1] - row
-                    pieces.append(chunk[lo:lo + room])
-                    lo += room
-                for piece in pieces:
+            for piece, ready in plan:
+                if piece is not None:
                     r0 = piece[0]
                     refs = [self._slot[jobs[j][0]] for j in piece]
                     srcs = [[self._slot[s] for s in jobs[j][1]] for j in piece]
                     eng.patchmatch_device(refs, srcs, self._pm_params(), self.seed_for_stream(),
                                           depth[r0].data_ptr(), normal[r0].data_ptr(), conf[r0].data_ptr())
-                    done_rows = piece[-1] - base + 1
-                    while next_group < n_groups and (done_rows >= groups[next_group][1] or done_rows == len(mine)):
-                        swept = torch.cuda.Event()
-                        swept.record(sweep_stream)
-                        gather_group(*groups[next_group], swept)
-                        next_group += 1
-            while next_group < n_groups:                  # a rank without views still takes part in every collective
-                swept = torch.cuda.Event()
-                swept.record(sweep_stream)
-                gather_group(*groups[next_group], swept)
-                next_group += 1
+                for g in ready:                           # (a rank without views still takes part in every collective)
+                    swept = torch.cuda.Event()
+                    swept.record(sweep_stream)
+                    gather_group(*groups[g], swept)
             for w in works:
                 w.wait()                                  # torch's current stream waits for the collective
             eng.sync()

@@ -299,3 +299,47 @@ def test_engine_cache_follows_the_poses(monkeypatch, scene_a):
     assert np.allclose(uploads[-scene_a.n + 1][1], moved[1].t)
     pm._patchmatch_cuda(2, [1, 3], dict(images), moved)            # an equal but different dict object
     assert len(uploads) == 3 * scene_a.n
+
+
+def test_group_launch_plan_is_consistent_across_ranks():
+    """PatchMatchMVS._plan_group_launches (the several-rank _sweep_resident): for many scene sizes, world
+    sizes, batch caps and source-count patterns every rank issues the same sequence of group gathers, each
+    group exactly once and only after the launches that cover its rows; every job of a rank is launched
+    exactly once, launches hold consecutive jobs of one source count, stay inside one row group and within
+    the cap.  (The RCCL collectives of the ranks must match one for one -- this is the part of the
+    multi-GPU path that no one-GPU box can execute with real peers.)"""
+    import amvs
+    from amvs.parallel import shard
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 4, 5, 7, 8, 16, 17, 32, 33, 64):
+        for world in (1, 2, 3, 4, 8):
+            for cap in (1, 2, 4, 16):
+                counts = rng.choice([2, 3, 4], size=n, p=[0.1, 0.2, 0.7])
+                jobs = [(j, list(range(int(counts[j])))) for j in range(n)]
+                per = -(-n // world)
+                seqs = []
+                for rank in range(world):
+                    mine = shard(n, rank, world)
+                    base = rank * per
+                    groups, plan = pm._plan_group_launches(jobs, mine, per, base, cap)
+                    assert groups[0][0] == 0 and groups[-1][1] == per
+                    assert all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+                    launched, gathered, rows_done = [], [], 0
+                    for piece, ready in plan:
+                        if piece is not None:
+                            assert 1 <= len(piece) <= cap
+                            assert piece == list(range(piece[0], piece[0] + len(piece)))
+                            assert len({len(jobs[j][1]) for j in piece}) == 1
+                            g0 = [g for g, (a, b) in enumerate(groups) if a <= piece[0] - base < b]
+                            g1 = [g for g, (a, b) in enumerate(groups) if a <= piece[-1] - base < b]
+                            assert g0 == g1 and len(g0) == 1, "a launch straddles a group boundary"
+                            launched += piece
+                            rows_done = piece[-1] - base + 1
+                        for g in ready:
+                            assert rows_done >= min(groups[g][1], len(mine)), "group gathered before it was swept"
+                            gathered.append(g)
+                    assert launched == mine, (n, world, cap, rank)
+                    assert gathered == list(range(len(groups))), (n, world, cap, rank, gathered)
+                    seqs.append((groups, gathered))
+                assert all(s == seqs[0] for s in seqs), "ranks disagree about the collectives"
