@@ -24,9 +24,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
+SIZE = [7, 120, 160]          # views, height, width of the scene (the larger two-rank test overrides it)
+
+
 def _scene():
     from amvs.synthetic import make_scene
-    return make_scene(7, 120, 160, seed=17)
+    return make_scene(SIZE[0], SIZE[1], SIZE[2], seed=17)
 
 
 def _run(extended=True, iterations=4):
@@ -94,10 +97,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, size=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if size:
+        SIZE[:] = size
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -123,6 +128,48 @@ def test_extended_mode_two_ranks_all_gather_between_iterations():
         assert p.exitcode == 0
     for rank, pts, cols in results:
         assert np.array_equal(pts, single_pts) and np.array_equal(cols, single_cols), f"rank {rank}"
+
+
+@pytest.mark.timeout(600)
+def test_extended_mode_two_ranks_at_a_size_where_the_exchange_takes_milliseconds():
+    """the scatter of the gathered rows into the state tensors runs on torch's stream while the
+    engine launches on its own; at 5 views of 540x960 (2 MB per map, 10 MB of normals per exchange) an
+    unsynchronised exchange would race with the next iteration's kernels.  Same cloud as one process."""
+    import torch.multiprocessing as mp
+    size = [5, 540, 960]
+    old = list(SIZE)
+    SIZE[:] = size
+    try:
+        _, _, single_pts, single_cols = _run(iterations=3)
+    finally:
+        SIZE[:] = old
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, 2, port, q, size)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(single_pts) > 1000
+    for rank, pts, cols in results:
+        assert np.array_equal(pts, single_pts) and np.array_equal(cols, single_cols), f"rank {rank}"
+
+
+def _worker3(rank, world, port, q, size):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    SIZE[:] = size
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, _, pts, cols = _run(iterations=3)
+        q.put((rank, pts, cols))
+    finally:
+        dist.destroy_process_group()
 
 
 def _engine_level_run(patch, stride, force_f32, iters=3):
