@@ -1,16 +1,20 @@
 #!/bin/bash
-# One GPU cycle for a finished build: GPU tests, rocprofv3 profiles of both sweeps, both benches.
-# Run under gpurun from the repository root.
+# One GPU cycle for a finished build (run under gpurun from the repository root): GPU tests, the
+# rocprofv3 profiles of both sweeps in both arithmetic modes (summaries -> profiles/ with
+# tools/profile_summary.py afterwards, see its header), the default bench, the rehearsals of the N > 1
+# path, the randomised parity sweeps.  Every step stops the cycle on failure.
 export TMPDIR=/tmp
-cd "${GRAFT_REPO_ROOT:-$PWD}"
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -5 gpurun_out/gpu_tests.log; exit 1; }
+cd "${GRAFT_REPO_ROOT:-$PWD}" || exit 1
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -5 gpurun_out/gpu_tests.log; exit 1; }
 tail -1 gpurun_out/gpu_tests.log
-rm -rf gpurun_out/prof gpurun_out/prof_pm gpurun_out/prof_ps
-tools/profile.sh > gpurun_out/profile.log 2>&1 || exit 1
-mv gpurun_out/prof gpurun_out/prof_pm
-BENCH_ARGS="--workload planesweep" tools/profile.sh > gpurun_out/profile_ps.log 2>&1 || exit 1
-mv gpurun_out/prof gpurun_out/prof_ps
-timeout -k 10 300 python bench.py > gpurun_out/bench_full.log 2>&1 || exit 1
-tail -1 gpurun_out/bench_full.log | cut -c1-160
-timeout -k 10 300 python bench.py --workload planesweep > gpurun_out/bench_ps.log 2>&1 || exit 1
-tail -1 gpurun_out/bench_ps.log | cut -c1-160
+PROF_TAG=pm_fast  BENCH_ARGS="--no-planesweep"                     tools/profile.sh > gpurun_out/profile_pm_fast.log 2>&1 || exit 1
+PROF_TAG=pm_exact BENCH_ARGS="--no-planesweep --mode exact"        tools/profile.sh > gpurun_out/profile_pm_exact.log 2>&1 || exit 1
+PROF_TAG=ps_fast  BENCH_ARGS="--workload planesweep"               tools/profile.sh > gpurun_out/profile_ps_fast.log 2>&1 || exit 1
+PROF_TAG=ps_exact BENCH_ARGS="--workload planesweep --mode exact"  tools/profile.sh > gpurun_out/profile_ps_exact.log 2>&1 || exit 1
+timeout -k 10 400 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err || exit 1
+cut -c1-200 gpurun_out/bench_full.json
+timeout -k 10 600 bash tools/r3_rehearse_2rank.sh > gpurun_out/rehearse.log 2>&1 || { tail -5 gpurun_out/rehearse.log; exit 1; }
+timeout -k 10 600 python tools/fuzz_parity.py --cases 80 > gpurun_out/fuzz_pm.log 2>&1 || { tail -3 gpurun_out/fuzz_pm.log; exit 1; }
+timeout -k 10 600 python tools/fuzz_parity.py --sweep --cases 60 > gpurun_out/fuzz_ps.log 2>&1 || { tail -3 gpurun_out/fuzz_ps.log; exit 1; }
+echo cycle-ok
