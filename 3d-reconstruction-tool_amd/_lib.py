@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 
 AMVS_MAX_SRC = 6
 MODES = {"default": 0, "exact": 1, "fast": 2}
-SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2, "split": 3}
+SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2, "split": 3, "paired": 4}
 SUPPORTED_PATCH_SIZES = (3, 5, 7, 9, 11)
 
 f32p = C.POINTER(C.c_float)

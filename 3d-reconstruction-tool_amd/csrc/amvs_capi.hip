@@ -522,6 +522,7 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
         a.fast = fast;
         a.band_major = band_major;
+        a.paired = (p->schedule == AMVS_SCHEDULE_PAIRED && fast && amvs::step_fast_pair_supported(p->patch_size, n_src)) ? 1 : 0;
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;
@@ -985,7 +986,7 @@ static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if ((rc = upload_jobs(c, n_ref, ref_ids, src_ids, n_src, fast ? p->patch_size : 0))) return rc;
 
     const size_t hw = (size_t)c->H * c->W;
-    if (p->schedule < 0 || p->schedule > AMVS_SCHEDULE_SPLIT) return fail(c, AMVS_EINVAL, "unknown schedule");
+    if (p->schedule < 0 || p->schedule > AMVS_SCHEDULE_PAIRED) return fail(c, AMVS_EINVAL, "unknown schedule");
     if (p->schedule == AMVS_SCHEDULE_SPLIT && !fast)
         return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists in fast mode only");
     // Continuation: iterations first_iteration .. of a sweep whose earlier iterations a previous call ran

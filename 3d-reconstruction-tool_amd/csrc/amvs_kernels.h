@@ -93,6 +93,9 @@ struct StepArgs : StepArgsBase {
     // Resident workgroups per CU of this sweep launch (enforced through unused dynamic LDS: 160 KiB /
     // wg_cap per workgroup); 0 = the default of AMVS_DEFAULT_WGS_PER_CU.  Performance only.
     int wg_cap;
+    // Paired-band schedule of the fast step (pm_step_fast_kernel<..., PAIR = true>): 2 x 2 strips per
+    // workgroup, vertically adjacent bands exchange their boundary samples through LDS
+    int paired;
 };
 
 #define AMVS_DEFAULT_WGS_PER_CU 4
@@ -121,6 +124,7 @@ hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st);      // split schedule, first half
 hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st);
 int step_fast_waves_per_cu(int K, int S, int wg_cap = 0);
+bool step_fast_pair_supported(int K, int S);       // the paired-band schedule is compiled for this patch / source count
 // test hook: per-source samples [S][H*W] and validity bits [H*W] of job 0 at the depth map a.d_in;
 // a.TH carries k/2, a.mode selects the bounds (MODE_EVAL patch bounds, MODE_CONF image bounds,
 // MODE_EVAL + 100 depth test only = plane sweep)

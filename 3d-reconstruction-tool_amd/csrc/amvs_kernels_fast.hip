@@ -47,12 +47,20 @@ template <int S> struct FRing {
 
 template <int K, int S> struct StepLds {
     static constexpr unsigned STATIC = AMVS_WG_WAVES * ((FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u);
-    static unsigned extra(int wg_cap)
+    static constexpr unsigned XBUF = AMVS_WG_WAVES * (K / 2) * S * AMVS_WAVE * 4u;     // paired bands: the exchange rows
+    static unsigned extra(int wg_cap, bool pair = false)
     {
         const unsigned share = 160u * 1024u / (unsigned)(wg_cap > 0 ? wg_cap : AMVS_DEFAULT_WGS_PER_CU);
-        return STATIC < share ? share - STATIC : 0u;
+        const unsigned st = STATIC + (pair ? XBUF : 0u);
+        return st < share ? share - st : 0u;
     }
 };
+
+// the paired-band schedule is compiled where its exchange rows fit beside the rings at 4 workgroups per CU
+constexpr bool fast_pair_supported(int K, int S)
+{
+    return K <= 7 && S <= 4;
+}
 
 // the last K reference codes of a lane's column as packed bytes: the window occupies the TOP K
 // bytes of NB dwords (oldest first)
@@ -251,22 +259,30 @@ AMVS_DEV void fring_push(float *lring, int lane, int wslot, float (&ring_v)[FRin
 // k x k window sums of v, v*v and r*v (code units) for S sources: column sums top -> bottom (plain
 // sum for v, FMA chains for v*v and r*v), row sums right -> left as K-1 DPP wave shifts -- the
 // order of the exact kernels (and of the tests' CPU checker).
-template <int K, int S>
-AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr)[K],
+// REV: the rings were filled walking UP the image (paired-band schedule, bottom-up wave): ring entry i is
+// then row (K-1-i) of the window, and the column sums take them newest first -- the same top -> bottom
+// order of the same values.
+template <int K, int S, bool REV = false>
+AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr_in)[K],
                                const float (&ring_v)[FRing<S>::NR][K], int lane,
                                float (&bv)[S], float (&bvv)[S], float (&brv)[S])
 {
     constexpr int NL = FRing<S>::NL;
     int slot[K];
+    float rr[K];
 #pragma unroll
-    for (int i = 0; i < K; ++i) slot[i] = oldest + i >= K ? oldest + i - K : oldest + i;
+    for (int i = 0; i < K; ++i) {
+        const int j = REV ? K - 1 - i : i;              // window row i (top -> bottom) = ring age j
+        slot[i] = oldest + j >= K ? oldest + j - K : oldest + j;
+        rr[i] = rr_in[j];
+    }
     float cs[3 * S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         float vv[K];
 #pragma unroll
         for (int i = 0; i < K; ++i)
-            vv[i] = s < NL ? lring[(s * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][i];
+            vv[i] = s < NL ? lring[(s * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][REV ? K - 1 - i : i];
         float cv = vv[0];
         float cvv = vv[0] * vv[0];
         float crv = rr[0] * vv[0];
@@ -373,9 +389,16 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kern
 // ------------------------------------------------------------------ sweep step ---
 // PRE: the samples come from the sample maps written by pm_sample_fast_kernel (split schedule)
 // instead of being gathered here; everything after the sampling stage is the same code.
-template <int K, int S, int MODE_T, bool PRE = false>
+// PAIR (StepArgs::paired, AMVS_SCHEDULE_PAIRED): a workgroup is 2 strip columns x 2 vertically adjacent
+// bands.  The waves of the upper band walk DOWN, those of the lower band walk UP, so that both reach the
+// common boundary at the same time; there they exchange the samples of their last K/2 rows through LDS
+// and finish their last K/2 output rows from the partner's samples instead of sampling a halo of their own:
+// K/2 halo rows per strip instead of K - 1 (the samples, and every sum over them in the same top -> bottom
+// order, are those of the classic strips: bit-identical results).
+template <int K, int S, int MODE_T, bool PRE = false, bool PAIR = false>
 __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) void pm_step_fast_kernel(const StepArgs a)
 {
+    static_assert(!(PRE && PAIR), "the paired bands sample for themselves");
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));      // 1 / (k^2 * 255)
@@ -384,6 +407,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     __shared__ float lring_all[AMVS_WG_WAVES * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;
     __shared__ uint2 nq_all[AMVS_WG_WAVES * NQ];
+    __shared__ float xbuf_all[PAIR ? AMVS_WG_WAVES * HALF * S * AMVS_WAVE : 1];   // [wave][row][source][lane]
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
@@ -391,10 +415,27 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     uint2 *nq = nq_all + wv * NQ;
     int q_head = 0, q_tail = 0;
     const int tiles_per_job = a.tiles_x * a.tiles_y;
-    const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
-    if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
     int job_id, ty, tx;
-    strip_of(a, t, job_id, ty, tx);
+    bool paired = false;                       // this wave has a partner band to exchange with
+    int up = 0;                                // 1: the wave walks up the image (lower band of a pair)
+    if constexpr (PAIR) {
+        static_assert(AMVS_WG_WAVES == 4, "paired bands: 2 columns x 2 bands per workgroup");
+        const int col_pairs = (a.tiles_x + 1) / 2, pair_rows = (a.tiles_y + 1) / 2;
+        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        job_id = wg / (col_pairs * pair_rows);
+        const int rem = wg - job_id * (col_pairs * pair_rows);
+        const int py = rem / col_pairs, px = rem - py * col_pairs;
+        tx = 2 * px + (wv & 1);
+        up = wv >> 1;
+        ty = 2 * py + up;
+        paired = 2 * py + 1 < a.tiles_y;
+        if (job_id >= a.n_jobs || tx >= a.tiles_x || ty >= a.tiles_y) return;   // (the partner of an exiting wave exits too,
+                                                                                //  or runs unpaired: `paired` is false)
+    } else {
+        const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
+        if (t >= a.n_jobs * tiles_per_job) return;             // last workgroup only
+        strip_of(a, t, job_id, ty, tx);
+    }
 
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
@@ -423,7 +464,17 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     FastCol cols[S];
     fast_columns<S>(job, fx, cols);
     const bool col_in = (unsigned)xr < (unsigned)W;
-    const int rows = min(a.TH, H - y0) + 2 * HALF;
+    const int th_w = min(a.TH, H - y0);                        // output rows of this strip
+    // classic: all strips of a workgroup lie in one band and walk th_w + K - 1 rows.  PAIR: every wave of
+    // the workgroup runs the same a.TH + K - 1 steps (common barriers); a wave whose band is shorter idles
+    // first, so that the partners meet at their boundary in the same step
+    const int rows = PAIR ? a.TH + 2 * HALF : th_w + 2 * HALF;
+    const int idle_first = (PAIR && up) ? a.TH - th_w : 0;
+    const int n_loc = th_w + 2 * HALF;                         // steps this wave works
+    const int n_own = paired ? th_w + HALF : n_loc;            // ... of which it samples itself
+    const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
+    float *xmine = PAIR ? xbuf_all + wv * (HALF * S * AMVS_WAVE) : nullptr;
+    const float *xpartner = PAIR ? xbuf_all + (wv ^ 2) * (HALF * S * AMVS_WAVE) : nullptr;
 
     uint32_t rb[RefBytes<K>::NB];
     float ring_v[FRing<S>::NR][K];
@@ -446,7 +497,14 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
 #if AMVS_WG_WAVES > 1 && AMVS_WG_SYNC_ROWS > 0
         if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
 #endif
-        const int yr = y0 - HALF + r;
+        if constexpr (PAIR) {
+            // the partners have written the samples of their last K/2 own rows (steps TH .. TH + K/2 - 1)
+            if (r == a.TH + HALF) __syncthreads();
+        }
+        const int loc = r - idle_first;                        // this wave's step
+        if (PAIR && (loc < 0 || loc >= n_loc)) continue;        // (wave-uniform)
+        const int yr = PAIR ? y_start + dy * loc : y0 - HALF + r;
+        const bool own = !PAIR || loc < n_own;                  // sampled here, not taken from the partner
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
@@ -454,7 +512,13 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
         float v[S];
         unsigned okbits = 0u;
-        if constexpr (PRE) {
+        if (PAIR && !own) {
+            // a row of the partner band: its samples, taken at its own candidates, from LDS (the partner
+            // wrote them walking towards the boundary: the row next to it last)
+            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (S * AMVS_WAVE);
+#pragma unroll
+            for (int s = 0; s < S; ++s) v[s] = xp[s * AMVS_WAVE + lane];
+        } else if constexpr (PRE) {
             const uint32_t *__restrict__ sp = smp + (live ? pix : 0);
             uint32_t w[S];
 #pragma unroll
@@ -469,6 +533,13 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
             const float d_raw = d_in[inb ? pix + noff : 0];
             const float dc = candidate_depth(a, mode, inb, d_raw, h0);
             okbits = fast_sample_sources_checked<S, true>(job, fc, cols, (float)yr, dc, live, v);
+            if constexpr (PAIR) {
+                if (paired && loc >= n_own - HALF) {           // the last K/2 own rows: for the partner
+                    float *xm = xmine + (loc - (n_own - HALF)) * (S * AMVS_WAVE);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) xm[s * AMVS_WAVE + lane] = v[s];
+                }
+            }
         }
         const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
 
@@ -481,10 +552,10 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
         for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
         hist_h0[HALF] = h0;
 
-        if (r < 2 * HALF) continue;
+        if ((PAIR ? loc : r) < 2 * HALF) continue;
 
         // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
-        const int yc = yr - HALF;
+        const int yc = PAIR ? yr - dy * HALF : yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = outl ? yc * W + xc : 0;
@@ -506,7 +577,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
 #pragma unroll
         for (int i = 0; i < K; ++i) rr[i] = ref_bytes_get<K>(rb, i);
         float bvs[S], bvvs[S], brvs[S];
-        window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
+        if (PAIR && up) window_sums_fast<K, S, true>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
+        else window_sums_fast<K, S>(lring, wslot, rr, ring_v, lane, bvs, bvvs, brvs);
         const float m1 = mv1.x, v1 = mv1.y;
 
         float total = 0.0f, cnt = 0.0f;
@@ -888,6 +960,17 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
         else hipLaunchKernelGGL((pm_step_fast_kernel<K, S, -1, true>), grid, block, 0, st, a);
         return hipGetLastError();
     }
+    if constexpr (fast_pair_supported(K, S)) {
+        if (a.paired && (a.mode == MODE_REFINE || a.mode == MODE_PROP)) {
+            const int pwg = a.n_jobs * ((a.tiles_x + 1) / 2) * ((a.tiles_y + 1) / 2);
+            const unsigned PXL = StepLds<K, S>::extra(a.wg_cap, true);
+            if (a.mode == MODE_REFINE)
+                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE, false, true>), dim3(pwg), block, PXL, st, a);
+            else
+                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP, false, true>), dim3(pwg), block, PXL, st, a);
+            return hipGetLastError();
+        }
+    }
     const unsigned XL = StepLds<K, S>::extra(a.wg_cap);
     if (a.mode == MODE_REFINE) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE>), grid, block, XL, st, a);
     else if (a.mode == MODE_PROP) hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP>), grid, block, XL, st, a);
@@ -933,6 +1016,8 @@ int step_fast_waves_per_cu(int K, int S, int wg_cap)
     default: return 8;
     }
 }
+
+bool step_fast_pair_supported(int K, int S) { return patch_supported(K) && S >= 2 && S <= AMVS_KMAX_SRC && fast_pair_supported(K, S); }
 
 hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
 {

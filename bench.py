@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--split-groups", type=int, default=0, help="split schedule: view groups (0 = automatic)")
     ap.add_argument("--split-lds", type=int, default=0, help="split schedule: unused LDS bytes per sampling workgroup (0 = automatic)")
     ap.add_argument("--split-rows", type=int, default=0, help="split schedule: rows per sampling strip (0 = automatic)")
-    ap.add_argument("--schedule", choices=["auto", "view-major", "band-major", "split"], default="auto",
+    ap.add_argument("--schedule", choices=["auto", "view-major", "band-major", "split", "paired"], default="auto",
                     help="strip order of the sweep launches (amvs_pm_params.schedule)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")

@@ -204,11 +204,18 @@ def test_strip_orders_give_identical_maps(mode):
     with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=mode) as eng:
         for i in ids:
             eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
-        for schedule in ["view-major", "band-major"] + (["split"] if mode == "fast" else []):
+        for schedule in ["view-major", "band-major", "paired"] + (["split"] if mode == "fast" else []):
             p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule=schedule)
             maps[schedule] = eng.patchmatch(ids, sources, p, 11)
             rows[schedule] = eng.last_tile_rows()
+        if mode == "fast":
+            # paired bands with an even band count whose last band is short (540 = 33 x 16 + 12), an odd one
+            # (27 bands of 20 rows: the last band has no partner) and single-band strips (one band of 540)
+            for tr in (16, 20, 540):
+                p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule="paired", tile_rows=tr)
+                maps[f"paired/{tr}"] = eng.patchmatch(ids, sources, p, 11)
     assert rows["band-major"] != rows["view-major"], rows          # a different launch shape was really used
+    # (the paired-band schedule exists in the fast arithmetic; in exact it runs as view-major)
     for schedule in maps:
         for a, b, what in zip(maps["view-major"], maps[schedule], ("depth", "normal", "confidence")):
             _eq(b, a, f"{mode} {schedule} {what}")

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--mode", default="fast")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--json", default="")
+    ap.add_argument("--schedule", default="auto")
+    ap.add_argument("--views-per-launch", type=int, default=0)
     args = ap.parse_args()
     import torch
 
@@ -52,7 +54,7 @@ def main():
     normal = torch.empty((n, 3 * H * W), dtype=torch.float32, device=dev)
     conf = torch.empty((n, H * W), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    p = make_pm_params(7, 8, 8, sc.depth_min, sc.depth_max)
+    p = make_pm_params(7, 8, 8, sc.depth_min, sc.depth_max, schedule=args.schedule, views_per_launch=args.views_per_launch)
     eng.set_step_timing(True)
     iters, per_it = 8, 10
     results = {}
