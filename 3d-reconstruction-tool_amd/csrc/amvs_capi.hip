@@ -522,7 +522,12 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
         a.fast = fast;
         a.band_major = band_major;
-        a.paired = (p->schedule == AMVS_SCHEDULE_PAIRED && fast && amvs::step_fast_pair_supported(p->patch_size, n_src)) ? 1 : 0;
+        // paired bands: asked for, or the automatic choice where they were measured faster (round 3, fast
+        // arithmetic, one run per pair, G px-hyp/s paired / classic: k=7 1080p 43.3 / 41.9, k=5 47.3 / 46.2,
+        // k=3 51.2 / 52.0 -- a one-row halo leaves nothing to save --, 2560x1440 41.6 / 39.3, 8 views of
+        // 3840x2160 38.7 / 36.4, 32 views 43.0 / 41.7)
+        a.paired = ((p->schedule == AMVS_SCHEDULE_PAIRED || (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5)) &&
+                    fast && amvs::step_fast_pair_supported(p->patch_size, n_src)) ? 1 : 0;
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;

@@ -45,13 +45,23 @@ template <int S> struct FRing {
     static constexpr int NR = S - NL > 0 ? S - NL : 1;
 };
 
+// strip columns of a paired-band workgroup (x 2 bands = its waves): 2 -> 4 waves, 4 -> 8 waves
+#ifndef AMVS_PAIR_COLS
+#define AMVS_PAIR_COLS 2
+#endif
+constexpr int PAIR_WAVES = 2 * AMVS_PAIR_COLS;
+
 template <int K, int S> struct StepLds {
-    static constexpr unsigned STATIC = AMVS_WG_WAVES * ((FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u);
-    static constexpr unsigned XBUF = AMVS_WG_WAVES * (K / 2) * S * AMVS_WAVE * 4u;     // paired bands: the exchange rows
+    static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u;
+    static constexpr unsigned STATIC = AMVS_WG_WAVES * PER_WAVE;
+    static constexpr unsigned XBUF = (K / 2) * S * AMVS_WAVE * 4u;                     // paired bands: the exchange rows of a wave
     static unsigned extra(int wg_cap, bool pair = false)
     {
-        const unsigned share = 160u * 1024u / (unsigned)(wg_cap > 0 ? wg_cap : AMVS_DEFAULT_WGS_PER_CU);
-        const unsigned st = STATIC + (pair ? XBUF : 0u);
+        // wg_cap counts workgroups of AMVS_WG_WAVES waves; a paired workgroup of PAIR_WAVES waves takes
+        // the share of PAIR_WAVES / AMVS_WG_WAVES of them
+        const unsigned cap = (unsigned)(wg_cap > 0 ? wg_cap : AMVS_DEFAULT_WGS_PER_CU);
+        const unsigned share = pair ? 160u * 1024u * PAIR_WAVES / (cap * AMVS_WG_WAVES) : 160u * 1024u / cap;
+        const unsigned st = pair ? PAIR_WAVES * (PER_WAVE + XBUF) : STATIC;
         return st < share ? share - st : 0u;
     }
 };
@@ -396,18 +406,19 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kern
 // K/2 halo rows per strip instead of K - 1 (the samples, and every sum over them in the same top -> bottom
 // order, are those of the classic strips: bit-identical results).
 template <int K, int S, int MODE_T, bool PRE = false, bool PAIR = false>
-__global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) void pm_step_fast_kernel(const StepArgs a)
+__global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fast_min_waves(K, S)) void pm_step_fast_kernel(const StepArgs a)
 {
+    constexpr int WGW = PAIR ? PAIR_WAVES : AMVS_WG_WAVES;      // waves of this workgroup
     static_assert(!(PRE && PAIR), "the paired bands sample for themselves");
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));      // 1 / (k^2 * 255)
     constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));    // 1 / (k^2 * 255^2)
     constexpr int NL = FRing<S>::NL;
-    __shared__ float lring_all[AMVS_WG_WAVES * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
+    __shared__ float lring_all[WGW * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;
-    __shared__ uint2 nq_all[AMVS_WG_WAVES * NQ];
-    __shared__ float xbuf_all[PAIR ? AMVS_WG_WAVES * HALF * S * AMVS_WAVE : 1];   // [wave][row][source][lane]
+    __shared__ uint2 nq_all[WGW * NQ];
+    __shared__ float xbuf_all[PAIR ? WGW * HALF * S * AMVS_WAVE : 1];             // [wave][row][source][lane]
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
@@ -419,14 +430,14 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     bool paired = false;                       // this wave has a partner band to exchange with
     int up = 0;                                // 1: the wave walks up the image (lower band of a pair)
     if constexpr (PAIR) {
-        static_assert(AMVS_WG_WAVES == 4, "paired bands: 2 columns x 2 bands per workgroup");
-        const int col_pairs = (a.tiles_x + 1) / 2, pair_rows = (a.tiles_y + 1) / 2;
+        constexpr int PC = AMVS_PAIR_COLS;                      // strip columns of a workgroup
+        const int col_pairs = (a.tiles_x + PC - 1) / PC, pair_rows = (a.tiles_y + 1) / 2;
         const int wg = xcd_remap(blockIdx.x, gridDim.x);
         job_id = wg / (col_pairs * pair_rows);
         const int rem = wg - job_id * (col_pairs * pair_rows);
         const int py = rem / col_pairs, px = rem - py * col_pairs;
-        tx = 2 * px + (wv & 1);
-        up = wv >> 1;
+        tx = PC * px + (wv % PC);
+        up = wv / PC;
         ty = 2 * py + up;
         paired = 2 * py + 1 < a.tiles_y;
         if (job_id >= a.n_jobs || tx >= a.tiles_x || ty >= a.tiles_y) return;   // (the partner of an exiting wave exits too,
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, fast_min_waves(K, S)) vo
     const int n_own = paired ? th_w + HALF : n_loc;            // ... of which it samples itself
     const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
     float *xmine = PAIR ? xbuf_all + wv * (HALF * S * AMVS_WAVE) : nullptr;
-    const float *xpartner = PAIR ? xbuf_all + (wv ^ 2) * (HALF * S * AMVS_WAVE) : nullptr;
+    const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * (HALF * S * AMVS_WAVE) : nullptr;
 
     uint32_t rb[RefBytes<K>::NB];
     float ring_v[FRing<S>::NR][K];
@@ -962,12 +973,13 @@ static hipError_t launch_step_fast_ks(const StepArgs &a, int nblk, hipStream_t s
     }
     if constexpr (fast_pair_supported(K, S)) {
         if (a.paired && (a.mode == MODE_REFINE || a.mode == MODE_PROP)) {
-            const int pwg = a.n_jobs * ((a.tiles_x + 1) / 2) * ((a.tiles_y + 1) / 2);
+            const int pwg = a.n_jobs * ((a.tiles_x + AMVS_PAIR_COLS - 1) / AMVS_PAIR_COLS) * ((a.tiles_y + 1) / 2);
             const unsigned PXL = StepLds<K, S>::extra(a.wg_cap, true);
+            const dim3 pblock(AMVS_WAVE * PAIR_WAVES);
             if (a.mode == MODE_REFINE)
-                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE, false, true>), dim3(pwg), block, PXL, st, a);
+                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_REFINE, false, true>), dim3(pwg), pblock, PXL, st, a);
             else
-                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP, false, true>), dim3(pwg), block, PXL, st, a);
+                hipLaunchKernelGGL((pm_step_fast_kernel<K, S, MODE_PROP, false, true>), dim3(pwg), pblock, PXL, st, a);
             return hipGetLastError();
         }
     }
