@@ -309,6 +309,8 @@ int resolve_fast(amvs_ctx *c, int requested, int *fast)
 // relatively longer tail than one of six, which is what the wider images, the larger patches and the
 // slower exact kernel lose more to than the L2 returns.  Hence groups of four exactly where they were
 // measured to win, else the whole batch (capped so that the per-launch state stays in the low GB).
+// Paired bands (round 3, later; bench.py, G px-hyp/s, groups of four / whole batch): 16 views 43.3 / 43.2,
+// 8 views 44.2 / 42.3, k=5 47.2 / 45.9 -- the same rule holds.
 int default_views_per_launch(const amvs_ctx *c, int n_ref, int patch, bool fast)
 {
     if (fast && patch <= 7 && c->W <= 2048 && n_ref >= 8 && n_ref % 4 == 0) return 4;
@@ -327,15 +329,22 @@ int default_views_per_launch(const amvs_ctx *c, int n_ref, int patch, bool fast)
 // -- the winners are the heights whose wave count is just below a whole number of generations
 // (or at least 3/4 of one).  Hence: among the heights up to `tall`, the best product of the last
 // generation's fill and the strip's useful fraction rows / (rows + patch - 1).
+// Paired bands (`paired`): a pair of bands samples 2 th + patch - 1 rows for 2 th output rows (an odd last
+// band keeps the classic th + patch - 1), and the locality cap is lower -- measured, 16 views 1080p, k=7, ms
+// per launch by band rows 12 / 14 / 16 / 18 / 20 / 22 / 24 / 27 / 30 / 36: 0.761 / 0.755 / 0.750 / 0.749 /
+// 0.751 / 0.755 / 0.762 / 0.761 / 0.765 / 0.780 -> 3 * patch - 3; k=5 in groups of 4 views: 12 rows 47.2, 16 rows
+// 44.0 G px-hyp/s; 2560x1440: 12 / 16 / 18 rows 40.5 / 41.1 / 41.3; 8 views 3840x2160: 38.5 / 38.4 / 38.2 (the
+// reduction for wide images applies beyond 3072 columns only).
 int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requested, int cap, bool fast = false,
-                   int wg_cap = 0)
+                   int wg_cap = 0, bool paired = false)
 {
     if (requested > 0) return requested < cap ? requested : cap;
     const int tiles_x = (c->W + amvs::strip_out_width(patch) - 1) / amvs::strip_out_width(patch);
     const long long slots = (long long)c->n_cu * (fast ? amvs::step_fast_waves_per_cu(patch, n_src, wg_cap)
                                                        : amvs::step_waves_per_cu(patch, n_src, usable_pairs(c) != nullptr, wg_cap));
     int tall = 4 * patch - 4 > 12 ? 4 * patch - 4 : 12;
-    if (c->W > 2048) tall = tall * 2 / 3 > 8 ? tall * 2 / 3 : 8;
+    if (paired) tall = 3 * patch - 3 > 8 ? 3 * patch - 3 : 8;
+    if (c->W > (paired ? 3072 : 2048)) tall = tall * 2 / 3 > 8 ? tall * 2 / 3 : 8;
     if (tall > cap) tall = cap;
     int best = tall < 8 ? tall : 8;
     double best_score = -1.0;
@@ -343,7 +352,13 @@ int pick_tile_rows(const amvs_ctx *c, int patch, int n_src, int n_jobs, int requ
         const double waves = (double)n_jobs * tiles_x * ((c->H + th - 1) / th);
         const double g = waves / (double)slots;
         const double fill = g > 1.0 ? g / std::ceil(g) : (g >= 0.75 ? 1.0 : g / 0.75);
-        const double score = fill * (double)th / (double)(th + patch - 1);
+        double useful = (double)th / (double)(th + patch - 1);
+        if (paired) {
+            const int bands = (c->H + th - 1) / th;
+            const double sampled = (double)(bands / 2) * (2 * th + patch - 1) + (double)(bands % 2) * (th + patch - 1);
+            useful = (double)c->H / sampled;
+        }
+        const double score = fill * useful;
         if (score > best_score + 1e-9) { best_score = score; best = th; }
     }
     return best;
@@ -487,11 +502,17 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     const size_t hw = (size_t)c->H * c->W;
     // Views per launch: the views of a batch are independent, so the batch can be swept in groups of
     // `vpl` views, each group through the whole schedule (see default_views_per_launch).
+    const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
+    // paired bands: asked for, or the automatic choice where they were measured faster (round 3, fast
+    // arithmetic, one run per pair, G px-hyp/s paired / classic: k=7 1080p 43.3 / 41.9, k=5 47.3 / 46.2,
+    // k=3 51.2 / 52.0 -- a one-row halo leaves nothing to save --, 2560x1440 41.6 / 39.3, 8 views of
+    // 3840x2160 38.7 / 36.4, 32 views 43.0 / 41.7)
+    const bool paired = (p->schedule == AMVS_SCHEDULE_PAIRED || (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5)) &&
+                        fast && amvs::step_fast_pair_supported(p->patch_size, n_src);
     int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref, p->patch_size, fast != 0);
     if (vpl > n_ref) vpl = n_ref;
-    const int band_major = p->schedule == 0 ? c->default_band_major : (p->schedule == 2);
     const int TH = p->tile_rows > 0 || !band_major
-                       ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0)
+                       ? pick_tile_rows(c, p->patch_size, n_src, vpl, p->tile_rows, 1 << 20, fast != 0, 0, paired)
                        : pick_band_rows(c, p->patch_size, n_src, vpl, fast != 0);
     c->last_tile_rows = TH;
     // launch shape of every step: strip rows and resident workgroups per CU (step_shape)
@@ -522,12 +543,7 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         amvs::StepArgs a = base_args(c, p->patch_size, nj, TH);
         a.fast = fast;
         a.band_major = band_major;
-        // paired bands: asked for, or the automatic choice where they were measured faster (round 3, fast
-        // arithmetic, one run per pair, G px-hyp/s paired / classic: k=7 1080p 43.3 / 41.9, k=5 47.3 / 46.2,
-        // k=3 51.2 / 52.0 -- a one-row halo leaves nothing to save --, 2560x1440 41.6 / 39.3, 8 views of
-        // 3840x2160 38.7 / 36.4, 32 views 43.0 / 41.7)
-        a.paired = ((p->schedule == AMVS_SCHEDULE_PAIRED || (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5)) &&
-                    fast && amvs::step_fast_pair_supported(p->patch_size, n_src)) ? 1 : 0;
+        a.paired = paired ? 1 : 0;
         a.jobs = c->d_jobs + j0;                   // slots stay global: job.slot = index in the batch
         a.depth_min = p->depth_min; a.depth_max = p->depth_max;
         a.seed = seed;

@@ -154,9 +154,9 @@ def test_config2_8x720p_plane_sweep_bit_exact(mode):
 
 def test_strip_height_follows_wave_quantisation(scene_1080):
     """pick_tile_rows (csrc/amvs_capi.hip): the automatic strip height makes the wave count of a launch
-    land just below a whole number of generations of resident waves (256 CUs x 16 waves) -- 24 rows for
-    the 16-view launch the bench times, 18 for 4 views, 24 for 2, 12 for one -- and the maps do not
-    depend on it."""
+    land just below a whole number of generations of resident waves (256 CUs x 16 waves) under the
+    locality cap of the paired-band schedule (3 k - 3 rows) -- 18 rows for 4 and for 2 views per launch,
+    12 for one -- and the maps do not depend on it."""
     import amvs
     from amvs.engine import make_pm_params
     sc = scene_1080
@@ -173,7 +173,7 @@ def test_strip_height_follows_wave_quantisation(scene_1080):
             p = make_pm_params(7, 1, 1, sc.depth_min, sc.depth_max, views_per_launch=n)
             maps[n] = eng.patchmatch(ids[:4], sources[:4], p, 3)
             got[n] = eng.last_tile_rows()
-    assert got == {16: 18, 4: 18, 2: 24, 1: 12}, got          # (a 4-view batch caps views_per_launch at 4)
+    assert got == {16: 18, 4: 18, 2: 18, 1: 12}, got          # (a 4-view batch caps views_per_launch at 4; paired bands)
     for n in (4, 2, 1):
         for a, b, what in zip(maps[16], maps[n], ("depth", "normal", "confidence")):
             _eq(b, a, f"{what}, {n} views per launch")

@@ -67,7 +67,10 @@ def main():
                 eng.patchmatch_device(ids[:n], sources[:n], p, 42, depth.data_ptr(), normal.data_ptr(), conf.data_ptr())
                 eng.sync()
                 t = eng.step_times()
-                assert len(t) == iters * per_it, len(t)
+                # groups of views run one after the other, each through the whole schedule: the time of a
+                # step is the sum over the groups (= per launch of all `n` views, as in the one-launch case)
+                assert len(t) % (iters * per_it) == 0, len(t)
+                t = np.asarray(t).reshape(-1, iters * per_it).sum(axis=0)
                 if rep > 0:
                     acc += t
             acc /= args.reps

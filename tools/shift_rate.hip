@@ -23,6 +23,15 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float c, const fl
             else if (KIND == 6) a[i] = __builtin_sqrtf(a[i] + c);                                                                       // IEEE sqrt expansion
             else if (KIND == 7) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x130, 0xf, 0xf, true));     // v_mov wave_shl
             else if (KIND == 8) a[i] = __shfl_down(a[i], 1) + c;
+            else if (KIND == 9) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x130, 0xf, 0xf, true)) + c;     // wave_shl:1 + add
+            else if (KIND == 10) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x111, 0xf, 0xf, true)) + c;    // row_shr:1 + add
+            else if (KIND == 11) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x138, 0xf, 0xf, true)) + c;    // wave_shr:1 + add
+            else if (KIND == 12) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x103, 0xf, 0xf, true)) + c;    // row_shl:3 + add
+            else if (KIND == 13) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x121, 0xf, 0xf, true)) + c;    // row_ror:1 + add
+            else if (KIND == 14) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x142, 0xa, 0xf, true)) + c;    // row_bcast:15 + add
+            else if (KIND == 15) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0x134, 0xf, 0xf, true)) + c;    // wave_rol:1 + add
+            else if (KIND == 16) a[i] = a[i] + c;                                                                                         // plain add
+            else if (KIND == 17) a[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0xB1, 0xf, 0xf, true)) + c;     // quad_perm [1,0,3,2] + add
         }
     }
     float s = 0; for (int i = 0; i < 16; ++i) s += a[i];
@@ -42,6 +51,9 @@ template <int KIND> void run(const char* name)
     hipFree(out); hipFree(lutg);
 }
 int main() {
+    run<16>("plain add"); run<9>("dpp wave_shl:1 + add"); run<10>("dpp row_shr:1 + add"); run<11>("dpp wave_shr:1 + add");
+    run<12>("dpp row_shl:3 + add"); run<13>("dpp row_ror:1 + add"); run<14>("dpp row_bcast:15 + add"); run<15>("dpp wave_rol:1 + add");
+    run<17>("dpp quad_perm + add");
     run<0>("dpp row_shl:1 + add"); run<7>("v_mov dpp wave_shl:1"); run<1>("ds_bpermute + add"); run<8>("__shfl_down + add");
     run<2>("lds lut read + add"); run<3>("v_rcp_f32 + add"); run<4>("v_sqrt_f32 + add"); run<5>("IEEE divide"); run<6>("add + IEEE sqrt");
     return 0;
