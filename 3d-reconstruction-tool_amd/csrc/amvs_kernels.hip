@@ -52,14 +52,20 @@ AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
     return c;
 }
 
+#ifndef AMVS_STEP_PRIO
+#define AMVS_STEP_PRIO true
+#endif
 // Sample all S sources of one pixel.
 // LEAN / `ok`: optimistic lean reciprocal (amvs_device.h).  SRC_CHECK = true tests `ok` after each
 // source's geometry and repeats that geometry with IEEE arithmetic (one wave-uniform branch per
 // source); SRC_CHECK = false leaves the test to the caller (one branch per row).
-template <int S, bool U8, bool LEAN, bool SRC_CHECK>
+// PRIO (the sweep step): raised issue priority from here until the gathers are requested -- see
+// fast_sample_sources (amvs_kernels_fast.hip).
+template <int S, bool U8, bool LEAN, bool SRC_CHECK, bool PRIO = false>
 AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
                                  Vec3 Pw, bool live, float (&v)[S], bool &ok)
 {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     unsigned okbits = 0u;
     JobCP jr = job;
     // the shared intrinsics: loaded once per row, with the reference pose (same scalar-load batch)
@@ -87,6 +93,7 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
         okbits |= valid ? (1u << s) : 0u;
         tr[s] = sample_load<U8>(c.img, tg[s], sc.W + 2 * AMVS_PAIR_BORDER);
     }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
     return okbits;
@@ -94,15 +101,15 @@ AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleC
 
 // Optimistic sampling of a row: lean arithmetic first; the IEEE repeat only when some lane's
 // projection depth left the range the lean reciprocal is verified for (amvs_device.h).
-template <int S, bool U8, bool ROW_CHECK>
+template <int S, bool U8, bool ROW_CHECK, bool PRIO = false>
 AMVS_DEV unsigned sample_sources_checked(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
                                          Vec3 Pw, bool live, float (&v)[S])
 {
     bool ok = true;
-    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true>(job, a, sc, lut, Pw, live, v, ok);
-    unsigned okbits = sample_sources<S, U8, true, false>(job, a, sc, lut, Pw, live, v, ok);
+    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true, PRIO>(job, a, sc, lut, Pw, live, v, ok);
+    unsigned okbits = sample_sources<S, U8, true, false, PRIO>(job, a, sc, lut, Pw, live, v, ok);
     if (__builtin_expect(!__all(ok), 0))
-        okbits = sample_sources<S, U8, false, false>(reload(job), a, sc, lut, Pw, live, v, ok);
+        okbits = sample_sources<S, U8, false, false, PRIO>(reload(job), a, sc, lut, Pw, live, v, ok);
     return okbits;
 }
 
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
 
         float v[S];
-        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING>(jr, a, sc, lut, Pw, live, v);
+        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING, AMVS_STEP_PRIO>(jr, a, sc, lut, Pw, live, v);
 
         // ---- push into the vertical rings ----
         ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
