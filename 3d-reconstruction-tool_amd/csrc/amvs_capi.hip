@@ -508,7 +508,8 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     // k=3 51.2 / 52.0 -- a one-row halo leaves nothing to save --, 2560x1440 41.6 / 39.3, 8 views of
     // 3840x2160 38.7 / 36.4, 32 views 43.0 / 41.7)
     const bool paired = (p->schedule == AMVS_SCHEDULE_PAIRED || (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5)) &&
-                        fast && amvs::step_fast_pair_supported(p->patch_size, n_src);
+                        (fast ? amvs::step_fast_pair_supported(p->patch_size, n_src)
+                              : (usable_pairs(c) != nullptr && amvs::step_pair_supported(p->patch_size, n_src)));
     int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref, p->patch_size, fast != 0);
     if (vpl > n_ref) vpl = n_ref;
     const int TH = p->tile_rows > 0 || !band_major

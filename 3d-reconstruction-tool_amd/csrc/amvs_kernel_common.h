@@ -120,6 +120,15 @@ AMVS_DEV void propagate_normals(const uint2 *nq, int head, int n, int lane, floa
 #ifndef AMVS_WG_SYNC_ROWS
 #define AMVS_WG_SYNC_ROWS 8
 #endif
+// Paired-band schedule (StepArgs::paired): a workgroup is AMVS_PAIR_COLS strip columns x 2 vertically
+// adjacent bands (2 -> 4 waves, 4 -> 8 waves); compiled where the exchange rows fit beside the rings at four
+// workgroups per CU
+#ifndef AMVS_PAIR_COLS
+#define AMVS_PAIR_COLS 2
+#endif
+constexpr int PAIR_WAVES = 2 * AMVS_PAIR_COLS;
+constexpr bool step_pair_supported_ks(int K, int S) { return K >= 5 && K <= 7 && S <= 4; }
+
 #if defined(AMVS_HSUM_LDS) && AMVS_WG_WAVES > 1
 #error "the LDS horizontal-sum variant keeps one exchange buffer per workgroup: build it with -DAMVS_WG_WAVES=1"
 #endif

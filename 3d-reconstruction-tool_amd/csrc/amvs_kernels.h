@@ -124,7 +124,8 @@ hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st);
 hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st);      // split schedule, first half
 hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st);
 int step_fast_waves_per_cu(int K, int S, int wg_cap = 0);
-bool step_fast_pair_supported(int K, int S);       // the paired-band schedule is compiled for this patch / source count
+bool step_fast_pair_supported(int K, int S);
+bool step_pair_supported(int K, int S);            // ... of the exact arithmetic (packed 8-bit maps)       // the paired-band schedule is compiled for this patch / source count
 // test hook: per-source samples [S][H*W] and validity bits [H*W] of job 0 at the depth map a.d_in;
 // a.TH carries k/2, a.mode selects the bounds (MODE_EVAL patch bounds, MODE_CONF image bounds,
 // MODE_EVAL + 100 depth test only = plane sweep)

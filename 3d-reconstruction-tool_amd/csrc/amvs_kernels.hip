@@ -165,7 +165,10 @@ AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], f
 }
 
 // `oldest` = LDS slot of the oldest row (the next write slot once the ring is full)
-template <int K, int S>
+// REV: the rings were filled walking UP the image (paired-band schedule, bottom-up wave): ring entry i is
+// then row (K-1-i) of the window, and the column sums take them newest first -- the same top -> bottom
+// order of the same values.
+template <int K, int S, bool REV = false>
 AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
                           const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
                           float (&bv)[S], float (&bvv)[S], float (&brv)[S], float &br, float &brr)
@@ -180,8 +183,9 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
     int slot[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        slot[i] = oldest + i >= K ? oldest + i - K : oldest + i;
-        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[i];
+        const int j = REV ? K - 1 - i : i;              // window row i (top -> bottom) = ring age j
+        slot[i] = oldest + j >= K ? oldest + j - K : oldest + j;
+        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[j];
     }
     // window sums of the reference image itself (r, r*r): the statistics mean1 / var1 of
     // mvs_patchmatch.py:403,406, recomputed from the ring (same order as box_stats_kernel, so the
@@ -200,7 +204,7 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
         float vv[K];
 #pragma unroll
         for (int i = 0; i < K; ++i)
-            vv[i] = s < NL ? lring[((s + 1) * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][i];
+            vv[i] = s < NL ? lring[((s + 1) * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][REV ? K - 1 - i : i];
         float cv = vv[0];
         float cvv = vv[0] * vv[0];
         float crv = rr[0] * vv[0];
@@ -281,9 +285,14 @@ constexpr int min_waves(int K, int S)
 // MODE_T: MODE_PROP / MODE_REFINE are compiled as their own kernels (99 % of the launches: the mode
 // switches, the other modes' code and, for propagation steps, the whole RNG hash fall away at
 // compile time); -1 is the generic kernel, used for MODE_EVAL and MODE_CONF.
-template <int K, int S, bool U8, int MODE_T>
-__global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm_step_kernel(const StepArgs a)
+// PAIR (StepArgs::paired, AMVS_SCHEDULE_PAIRED): 2 strip columns x 2 vertically adjacent bands per
+// workgroup; the bands walk towards each other and exchange the samples of their last K/2 rows through LDS
+// (K/2 halo rows per band instead of K - 1; same samples, same sums in the same order: bit-identical maps) --
+// see pm_step_fast_kernel (amvs_kernels_fast.hip), whose structure this follows.
+template <int K, int S, bool U8, int MODE_T, bool PAIR = false>
+__global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), min_waves(K, S)) void pm_step_kernel(const StepArgs a)
 {
+    constexpr int WGW = PAIR ? PAIR_WAVES : AMVS_WG_WAVES;      // waves of this workgroup
     constexpr int HALF = K / 2;
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float INV_AREA = 1.0f / (float)(K * K);
@@ -293,9 +302,11 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
 #else
     float4 *hbuf = nullptr;
 #endif
-    __shared__ float lring_all[AMVS_WG_WAVES * (Ring<S>::NL + 1) * K * AMVS_WAVE];
+    __shared__ float lring_all[WGW * (Ring<S>::NL + 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;                    // refinement winners waiting for their normal
-    __shared__ uint2 nq_all[AMVS_WG_WAVES * NQ];
+    __shared__ uint2 nq_all[WGW * NQ];
+    constexpr int XW = HALF * S * AMVS_WAVE;             // floats of a wave's exchange rows [row][source][lane]
+    __shared__ float xbuf_all[PAIR ? WGW * XW : 1];
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
@@ -305,10 +316,28 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
     const int tiles_per_job = a.tiles_x * a.tiles_y;
-    const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
-    if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
     int job_id, ty, tx;
-    strip_of(a, t, job_id, ty, tx);
+    bool paired = false;                       // this wave has a partner band to exchange with
+    int up = 0;                                // 1: the wave walks up the image (lower band of a pair)
+    if constexpr (PAIR) {
+        constexpr int PC = AMVS_PAIR_COLS;
+        const int col_pairs = (a.tiles_x + PC - 1) / PC, pair_rows = (a.tiles_y + 1) / 2;
+        const int wg = xcd_remap(blockIdx.x, gridDim.x);
+        job_id = wg / (col_pairs * pair_rows);
+        const int rem = wg - job_id * (col_pairs * pair_rows);
+        const int py = rem / col_pairs, px = rem - py * col_pairs;
+        tx = PC * px + (wv % PC);
+        up = wv / PC;
+        ty = 2 * py + up;
+        paired = 2 * py + 1 < a.tiles_y;
+        // (every wave fills the decode table first; a wave without a strip leaves before the first barrier of
+        //  the row loop, as do the partners of an odd last band that does not exist)
+        if (job_id >= a.n_jobs || tx >= a.tiles_x || ty >= a.tiles_y) return;
+    } else {
+        const int t = xcd_remap(blockIdx.x, gridDim.x) * AMVS_WG_WAVES + wv;
+        if (t >= a.n_jobs * tiles_per_job) return;                 // last workgroup only
+        strip_of(a, t, job_id, ty, tx);
+    }
 
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
@@ -341,7 +370,16 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
     const int y0 = ty * a.TH;
     const int xr = xbase + lane;
     const bool col_in = (unsigned)xr < (unsigned)W;
-    const int rows = min(a.TH, H - y0) + 2 * HALF;
+    const int th_w = min(a.TH, H - y0);                        // output rows of this strip
+    // classic: th_w + K - 1 rows.  PAIR: every wave of the workgroup runs the same a.TH + K - 1 steps (common
+    // barriers); a wave whose band is shorter idles first, so that the partners meet at their boundary
+    const int rows = PAIR ? a.TH + 2 * HALF : th_w + 2 * HALF;
+    const int idle_first = (PAIR && up) ? a.TH - th_w : 0;
+    const int n_loc = th_w + 2 * HALF;                         // steps this wave works
+    const int n_own = paired ? th_w + HALF : n_loc;            // ... of which it samples itself
+    const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
+    float *xmine = PAIR ? xbuf_all + wv * XW : nullptr;
+    const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * XW : nullptr;
 
     float ring_r[K];
     float ring_v[Ring<S>::NR][K];
@@ -373,7 +411,14 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         // strips of different heights in one workgroup are fine)
         if (r % AMVS_WG_SYNC_ROWS == 0) __builtin_amdgcn_s_barrier();
 #endif
-        const int yr = y0 - HALF + r;
+        if constexpr (PAIR) {
+            // the partners have written the samples of their last K/2 own rows (steps TH .. TH + K/2 - 1)
+            if (r == a.TH + HALF) __syncthreads();
+        }
+        const int loc = r - idle_first;                        // this wave's step
+        if (PAIR && (loc < 0 || loc >= n_loc)) continue;        // (wave-uniform)
+        const int yr = PAIR ? y_start + dy * loc : y0 - HALF + r;
+        const bool own = !PAIR || loc < n_own;                  // sampled here, not taken from the partner
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
@@ -396,11 +441,26 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
             dc = mode == MODE_REFINE ? d : dc;
         }
         const float rv = live ? r_raw : 0.0f;
-        JobCP jr = reload(job);
-        const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
-
         float v[S];
-        const unsigned okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING, AMVS_STEP_PRIO>(jr, a, sc, lut, Pw, live, v);
+        unsigned okbits = 0u;
+        if (PAIR && !own) {
+            // a row of the partner band: its samples, taken at its own candidates, from LDS (the partner
+            // wrote them walking towards the boundary: the row next to it last)
+            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (S * AMVS_WAVE);
+#pragma unroll
+            for (int s = 0; s < S; ++s) v[s] = xp[s * AMVS_WAVE + lane];
+        } else {
+            JobCP jr = reload(job);
+            const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
+            okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING, AMVS_STEP_PRIO>(jr, a, sc, lut, Pw, live, v);
+            if constexpr (PAIR) {
+                if (paired && loc >= n_own - HALF) {           // the last K/2 own rows: for the partner
+                    float *xm = xmine + (loc - (n_own - HALF)) * (S * AMVS_WAVE);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) xm[s * AMVS_WAVE + lane] = v[s];
+                }
+            }
+        }
 
         // ---- push into the vertical rings ----
         ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
@@ -410,10 +470,10 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         for (int i = 0; i < HALF; ++i) hist_h0[i] = hist_h0[i + 1];
         hist_h0[HALF] = h0;
 
-        if (r < 2 * HALF) continue;
+        if ((PAIR ? loc : r) < 2 * HALF) continue;
 
         // ---- window sums, NCC, aggregate for centre row yc and centre column xc ----
-        const int yc = yr - HALF;
+        const int yc = PAIR ? yr - dy * HALF : yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
         const int pc = outl ? yc * W + xc : 0;
@@ -432,7 +492,8 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES, min_waves(K, S)) void pm
         const uint32_t h0c = (uint32_t)__shfl_down((int)hist_h0[0], HALF);
 
         float bvs[S], bvvs[S], brvs[S], br, brr;
-        window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
+        if (PAIR && up) window_sums<K, S, true>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
+        else window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
         const float m1 = br * INV_AREA;
         const float v1 = brr * INV_AREA - m1 * m1;
 
@@ -994,6 +1055,19 @@ static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
     const dim3 grid(nwg), block(AMVS_WAVE * AMVS_WG_WAVES);
 #define AMVS_LAUNCH_STEP(U8, M) \
     hipLaunchKernelGGL((pm_step_kernel<K, S, U8, M>), grid, block, (step_extra_lds<&pm_step_kernel<K, S, U8, M>>(a.wg_cap)), st, a)
+    if constexpr (step_pair_supported_ks(K, S)) {
+        if (a.pairs && a.paired && (a.mode == MODE_REFINE || a.mode == MODE_PROP)) {
+            const int pwg = a.n_jobs * ((a.tiles_x + AMVS_PAIR_COLS - 1) / AMVS_PAIR_COLS) * ((a.tiles_y + 1) / 2);
+            const dim3 pgrid(pwg), pblock(AMVS_WAVE * PAIR_WAVES);
+            if (a.mode == MODE_REFINE)
+                hipLaunchKernelGGL((pm_step_kernel<K, S, true, MODE_REFINE, true>), pgrid, pblock,
+                                   (step_extra_lds<&pm_step_kernel<K, S, true, MODE_REFINE, true>>(a.wg_cap)), st, a);
+            else
+                hipLaunchKernelGGL((pm_step_kernel<K, S, true, MODE_PROP, true>), pgrid, pblock,
+                                   (step_extra_lds<&pm_step_kernel<K, S, true, MODE_PROP, true>>(a.wg_cap)), st, a);
+            return hipGetLastError();
+        }
+    }
     if (a.pairs) {
         if (a.mode == MODE_REFINE) AMVS_LAUNCH_STEP(true, MODE_REFINE);
         else if (a.mode == MODE_PROP) AMVS_LAUNCH_STEP(true, MODE_PROP);
@@ -1053,6 +1127,7 @@ int step_waves_per_cu(int K, int S, bool u8, int wg_cap)
 }
 
 bool patch_supported(int K) { return K == 3 || K == 5 || K == 7 || K == 9 || K == 11; }
+bool step_pair_supported(int K, int S) { return patch_supported(K) && S >= 2 && S <= AMVS_KMAX_SRC && step_pair_supported_ks(K, S); }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)

@@ -45,11 +45,6 @@ template <int S> struct FRing {
     static constexpr int NR = S - NL > 0 ? S - NL : 1;
 };
 
-// strip columns of a paired-band workgroup (x 2 bands = its waves): 2 -> 4 waves, 4 -> 8 waves
-#ifndef AMVS_PAIR_COLS
-#define AMVS_PAIR_COLS 2
-#endif
-constexpr int PAIR_WAVES = 2 * AMVS_PAIR_COLS;
 
 template <int K, int S> struct StepLds {
     static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u;

@@ -63,9 +63,9 @@ def test_config3_16x1080p_batch_bit_exact(scene_1080, mode):
         assert eng.sampling_mode() == "u8-pairs"
         p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max)
         depth, normal, conf = eng.patchmatch(ids, sources, p, 42)
-        # the bench's launch shape: fast arithmetic in groups of 4 views with 18-row strips (two full
-        # generations of waves), exact arithmetic as the whole batch with 24-row strips
-        assert (eng.last_views_per_launch(), eng.last_tile_rows()) == ((4, 18) if mode == "fast" else (16, 24))
+        # the bench's launch shape: paired bands of 18 rows; fast arithmetic in groups of 4 views (two full
+        # generations of waves), exact arithmetic as the whole batch
+        assert (eng.last_views_per_launch(), eng.last_tile_rows()) == ((4, 18) if mode == "fast" else (16, 18))
     for r in (0, 9, 15):                                             # first, interior and last slot of the batch
         od, on, oc = _oracle_ctx(sc, r, sources[r], 7, mode).patchmatch(1, 2, sc.depth_min, sc.depth_max, 42, r)
         _eq(depth[r], od, f"{mode} 1080p view {r} depth")
