@@ -49,9 +49,12 @@ def kernel_source_hash(kernel_key):
     are not replayed against a newer build."""
     import hashlib
     csrc = os.path.join(ROOT, "3d-reconstruction-tool_amd", "csrc")
-    main = "amvs_kernels_fast.hip" if "_fast_" in kernel_key else "amvs_kernels.hip"
+    if "_fast_" in kernel_key:
+        names = ("amvs_sweep_fast.hip" if kernel_key.startswith("plane_sweep") else "amvs_kernels_fast.hip", "amvs_fast_common.h")
+    else:
+        names = ("amvs_kernels.hip",)
     h = hashlib.sha1()
-    for name in (main, "amvs_kernel_common.h", "amvs_device.h", "amvs_kernels.h"):
+    for name in names + ("amvs_kernel_common.h", "amvs_device.h", "amvs_kernels.h"):
         with open(os.path.join(csrc, name), "rb") as f:
             data = f.read()
         h.update(hashlib.sha1(b"blob %d\0" % len(data) + data).digest())
