@@ -30,6 +30,7 @@ through amvs_get_timing), -- at N=1 -- the CPU oracle (same arithmetic mode) tim
 cores on a bounded sample of the same workload, and a `planesweep` sub-record (BASELINE config 2).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -464,6 +465,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    gc.collect()                 # (no cyclic garbage collection inside the timed region, as timeit does)
+    gc.disable()
     for _ in range(args.warmup):
         step()
     fence()
@@ -482,6 +485,7 @@ def main():
         launches += t["sweep_launches"] * calls
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     # one step from an idle pipeline, its exchange (and fusion) inside: the latency of one reconstruct
     t1 = time.perf_counter()
     step()
@@ -595,7 +599,10 @@ def main():
         if world == 1 and not args.no_planesweep:
             # BASELINE config 2 beside it: a few steps (about 10 ms each) and a short CPU leg
             torch.cuda.empty_cache()
-            out["planesweep"] = run_planesweep(args, steps=5, warmup=1, with_cpu=not args.no_cpu_baseline, cpu_reps=3)
+            # a plane-sweep step is ~6.5 ms: 8 untimed steps (~55 ms, what ONE warm-up step of the main line
+            # takes) before the 10 timed ones -- after a single 7 ms step the device is still ramping
+            # (launches under the tracer: 7.46 7.01 6.68 6.39 6.37 6.35 ms, profiles/r03_plane_sweep_fast.txt)
+            out["planesweep"] = run_planesweep(args, steps=10, warmup=8, with_cpu=not args.no_cpu_baseline, cpu_reps=3)
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
@@ -644,16 +651,28 @@ def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
         eng.plane_sweep_device(refs, nb, depths, patch, 0.8, dmap.data_ptr(), conf.data_ptr())
         eng.sync()
 
+    # (no cyclic garbage collection inside the timed region, as timeit does: a full collection of the
+    #  interpreter's ~10^6 live objects took 40 ms -- six plane-sweep steps -- when it fell into one; collected
+    #  BEFORE the warm-up steps, so that the device does not idle between them and the timed ones)
+    gc.collect()
+    gc.disable()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kernel_ms = 0.0
+    trace = []
     for _ in range(steps):
+        ts = time.perf_counter()
         step()
+        tm = time.perf_counter()
         kernel_ms += eng.timing()["sweep_ms"]
+        trace.append((round((tm - ts) * 1e3, 2), round((time.perf_counter() - tm) * 1e3, 2)))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("AMVS_BENCH_TRACE"):
+        print("planesweep per step (step ms, timing() ms):", trace, file=sys.stderr)
     n_hyp = n_views * H * W * D
     value = n_hyp * steps / elapsed / 1e6
     bytes_per_hyp = 4 * S + 4 + 8.0 / D

@@ -10,8 +10,8 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log
 tail -1 gpurun_out/gpu_tests.log
 PROF_TAG=pm_fast  BENCH_ARGS="--no-planesweep"                     tools/profile.sh > gpurun_out/profile_pm_fast.log 2>&1 || exit 1
 PROF_TAG=pm_exact BENCH_ARGS="--no-planesweep --mode exact"        tools/profile.sh > gpurun_out/profile_pm_exact.log 2>&1 || exit 1
-PROF_TAG=ps_fast  BENCH_ARGS="--workload planesweep"               tools/profile.sh > gpurun_out/profile_ps_fast.log 2>&1 || exit 1
-PROF_TAG=ps_exact BENCH_ARGS="--workload planesweep --mode exact"  tools/profile.sh > gpurun_out/profile_ps_exact.log 2>&1 || exit 1
+PROF_TAG=ps_fast  BENCH_ARGS="--workload planesweep --steps 10 --warmup 8"               tools/profile.sh > gpurun_out/profile_ps_fast.log 2>&1 || exit 1
+PROF_TAG=ps_exact BENCH_ARGS="--workload planesweep --mode exact --steps 10 --warmup 8"  tools/profile.sh > gpurun_out/profile_ps_exact.log 2>&1 || exit 1
 timeout -k 10 400 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err || exit 1
 cut -c1-200 gpurun_out/bench_full.json
 timeout -k 10 600 bash tools/r3_rehearse_2rank.sh > gpurun_out/rehearse.log 2>&1 || { tail -5 gpurun_out/rehearse.log; exit 1; }
