@@ -438,39 +438,47 @@ class PatchMatchMVS:
         per = (n + world - 1) // world                    # rows per rank block (the last block may be short)
         base = rank * per
         groups, plan = self._plan_group_launches(jobs, mine, per, base, self.views_per_batch)
-        # job j lives in row j (blocks are contiguous in job order); rows >= n are padding
+        # Storage rows are laid out [group][rank][row of the group]: what one group's exchange fills is ONE
+        # contiguous block, so a group is one all_gather_into_tensor per map, in place (this rank's rows are
+        # its own slice of the block) -- no list of output views for ProcessGroupNCCL to assemble through a
+        # flattened scratch and copy out.  Job j = r * per + a + i (rank r, group [a, b), i < b - a) lives in
+        # storage row world * a + r * (b - a) + i; rows of jobs >= n are padding.
+        def store_row(j):
+            r, k = divmod(j, per)
+            a, b = next(g for g in groups if g[0] <= k < g[1])
+            return world * a + r * (b - a) + (k - a)
         depth = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
         normal = torch.zeros((world * per, 3 * hw), dtype=torch.float32, device=dev)
         conf = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
         maps = [depth, conf] + ([normal] if self.gather_normals else [])      # fusion reads the first two
-        sweep_stream = torch.cuda.Stream(device=dev)
-        comm_stream = torch.cuda.Stream(device=dev)
+        sweep_stream, comm_stream = self._exchange_streams(torch, dev)
         torch.cuda.synchronize(dev)                       # the zero fills ran on torch's current stream
         eng.set_stream(sweep_stream.cuda_stream)
         works = []
 
         def gather_group(a, b, swept):
             """All-gather rows [a, b) of every rank's block; `swept` = event after the launches that wrote them."""
+            blk0, rows = world * a, b - a
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(swept)
                 for t in maps:
-                    outs = [t[r * per + a: r * per + b] for r in range(world)]
+                    block = t[blk0: blk0 + world * rows]              # [rank][row], contiguous
+                    own = block[rank * rows: (rank + 1) * rows]
                     if direct:
-                        works.append(dist.all_gather(outs, t[base + a: base + b], group=self.process_group,
-                                                     async_op=True))
+                        works.append(dist.all_gather_into_tensor(block, own, group=self.process_group, async_op=True))
                     else:                                 # gloo (tests): staged through the host
                         swept.synchronize()
-                        host = [torch.empty((b - a, t.shape[1]), dtype=torch.float32) for _ in range(world)]
-                        dist.all_gather(host, t[base + a: base + b].cpu(), group=self.process_group)
+                        host = torch.empty((world * rows, t.shape[1]), dtype=torch.float32)
+                        dist.all_gather_into_tensor(host, own.cpu(), group=self.process_group)
                         for r in range(world):
                             if r != rank:
-                                outs[r].copy_(host[r])
+                                block[r * rows: (r + 1) * rows].copy_(host[r * rows: (r + 1) * rows])
 
         t1 = time.time()
         try:
             for piece, ready in plan:
                 if piece is not None:
-                    r0 = piece[0]
+                    r0 = store_row(piece[0])              # (a launch never straddles a group: consecutive storage rows)
                     refs = [self._slot[jobs[j][0]] for j in piece]
                     srcs = [[self._slot[s] for s in jobs[j][1]] for j in piece]
                     eng.patchmatch_device(refs, srcs, self._pm_params(), self.seed_for_stream(),
@@ -487,15 +495,28 @@ class PatchMatchMVS:
             torch.cuda.synchronize(dev)
         finally:
             eng.set_stream(None)
-        self._streams = (sweep_stream, comm_stream)       # (kept alive until the next call)
         per_view = (time.time() - t1) / max(len(mine), 1)
-        valid = (conf[:n] >= self.min_views).sum(dim=1).tolist()
+        # back to job order (the fusion walks the maps view by view: the cloud's point order depends on it)
+        order = torch.tensor([store_row(j) for j in range(n)], dtype=torch.long, device=dev)
+        identity = all(store_row(j) == j for j in range(n))
+        depth, conf = (depth[:n], conf[:n]) if identity else (depth.index_select(0, order), conf.index_select(0, order))
+        normal = normal[:n] if identity else normal.index_select(0, order)
+        valid = (conf >= self.min_views).sum(dim=1).tolist()
         for j in mine:
             ref_idx = jobs[j][0]
             print(f"  [{cam_indices.index(ref_idx)+1}/{n_cams}] Cam {ref_idx}: "
                   f"{int(valid[j]):,} valid pixels ({per_view:.1f}s)")
-        return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(n)], depth=depth[:n], normal=normal[:n],
-                             confidence=conf[:n], shape=(H, W))
+        return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(n)], depth=depth, normal=normal,
+                             confidence=conf, shape=(H, W))
+
+    def _exchange_streams(self, torch, dev):
+        """The sweep / exchange streams of the several-rank path, created once per device and reused by every
+        later reconstruct of this object."""
+        cached = getattr(self, "_streams", None)
+        if cached is None or cached[0] != dev:
+            cached = (dev, torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._streams = cached
+        return cached[1], cached[2]
 
     def _sweep_extended(self, torch, jobs, proc_images, poses, cam_indices) -> "_ResidentMaps":
         """The extended mode (csrc/amvs_extended.hip): the state of ALL views lives in device tensors;

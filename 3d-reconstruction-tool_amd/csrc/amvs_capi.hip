@@ -13,6 +13,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -632,6 +633,7 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
         c->ev_groups.push_back(ev);
     }
     c->timing_groups = 1;
+    c->n_step_events = 0;                       // (no per-launch events in this schedule: amvs_get_step_times returns none)
     // The window kernel gathers nothing, so its strips can be tall (vertical halo 1.09 at 64 rows);
     // the sampling kernel has no halo at all and wants SHORT strips (the resident waves then touch
     // fewer source rows at once).  Measured on MI355X, 16 views 1080p, k=7, S=4, 2 groups, ms per step:
@@ -685,10 +687,12 @@ int run_split_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     if (!sched.empty()) HIPCHK(c, hipStreamWaitEvent(c->stream, ev_windowed[G - 1], 0));
     HIPCHK(c, hipEventRecord(c->ev_groups[1], c->stream));
     // _compute_confidence (mvs_patchmatch.py:493-534): one fused launch over the whole batch
-    all.mode = amvs::MODE_CONF;
-    set_io(all, c, cur);
-    all.aux = conf_dev ? (float *)conf_dev : c->d_aux;
-    HIPCHK(c, amvs::launch_step(p->patch_size, n_src, all, c->stream));
+    if ((p->flags & AMVS_PM_NO_CONFIDENCE) == 0) {
+        all.mode = amvs::MODE_CONF;
+        set_io(all, c, cur);
+        all.aux = conf_dev ? (float *)conf_dev : c->d_aux;
+        HIPCHK(c, amvs::launch_step(p->patch_size, n_src, all, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_groups[2], c->stream));
     c->timing.sweep_launches = (int64_t)sched.size();     // one hypothesis of the whole batch each
     c->last_views_per_launch = n_ref;
@@ -1084,7 +1088,8 @@ int amvs_patchmatch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_i
                                          nullptr, nullptr, 0, c->stream));
     HIPCHK(c, hipMemcpyAsync(depth_out, c->d_depth[cur], 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(normal_out, c->d_normal[0], 12 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
+    if ((p->flags & AMVS_PM_NO_CONFIDENCE) == 0)
+        HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
     return AMVS_OK;
@@ -1251,6 +1256,7 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     resolve_timing(c);
     c->timing = amvs_timing{};
     c->timing_groups = 0;
+    c->n_step_events = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_keys, 0, sizeof(unsigned) * hw * n_ref, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1272,6 +1278,7 @@ int amvs_plane_sweep(amvs_ctx *c, int ref, const int *nbr_ids, int n_nbr, const 
     int rc = bind_device(c);
     if (rc) return rc;
     if ((rc = ensure_slots(c, 1))) return rc;
+    c->pm_resumable = false;                    // the maps below land in slot 0 of the PatchMatch state
     const size_t hw = (size_t)c->H * c->W;
     rc = amvs_plane_sweep_device(c, 1, &ref, nbr_ids, n_nbr, depths, D, patch_size, thresh,
                                  c->d_depth[0], c->d_aux);
@@ -1828,11 +1835,22 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl q;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            q.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (q.lib) break;
+        // AMVS_RCCL_LIB (read once, here): the library to open instead of the default names -- a site with
+        // RCCL elsewhere, and the test of the not-found path
+        const char *forced = std::getenv("AMVS_RCCL_LIB");
+        std::string last;
+        if (forced && *forced) {
+            q.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            if (!q.lib) { const char *e = dlerror(); last = e ? e : ""; }     // (dlerror() clears itself: call it once)
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                q.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (q.lib) break;
+                const char *e = dlerror();
+                last = e ? e : "";
+            }
         }
-        if (!q.lib) { q.why = std::string("RCCL not found (dlopen librccl.so.1): ") + (dlerror() ? dlerror() : ""); return q; }
+        if (!q.lib) { q.why = "RCCL not found (dlopen " + std::string(forced && *forced ? forced : "librccl.so.1") + "): " + last; return q; }
         q.GetUniqueId = (decltype(q.GetUniqueId))dlsym(q.lib, "ncclGetUniqueId");
         q.CommInitRank = (decltype(q.CommInitRank))dlsym(q.lib, "ncclCommInitRank");
         q.AllGather = (decltype(q.AllGather))dlsym(q.lib, "ncclAllGather");

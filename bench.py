@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the PatchMatch-MVS sweep on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without a launcher: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `--workload planesweep` benchmarks the sibling path instead (BASELINE config 2: 8 views of
@@ -167,6 +167,46 @@ def baseline_label(args, n_views, W, H, world):
     return "custom workload (no BASELINE config): "
 
 
+def launch_ranks(n):
+    """Run this script as n ranks of one node: n fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (what `python -m torch.distributed.run --nproc-per-node n` would set), the
+    same command line.  The parent never imports torch and never touches the GPU; it relays rank 0's
+    stdout (the ONE JSON line), sends the other ranks' stdout to stderr and returns non-zero if any rank
+    fails -- the remaining ranks (which would wait in a collective for ever) are then terminated by PID."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    q.terminate()
+                deadline = time.time() + 10
+                for q in alive:
+                    try:
+                        q.wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,6 +251,11 @@ def main():
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE config 5 preset: 64 views of 3840x2160 over the ranks, fusion inside the step")
     args = ap.parse_args()
+    # `python bench.py --gpus N` without a launcher (no WORLD_SIZE): start the N ranks here, as fresh child
+    # processes, BEFORE anything in this process touches torch or the GPU; this process only waits and
+    # relays rank 0's JSON line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("AMVS_BENCH_FORCE_EXCHANGE") != "1":
+        sys.exit(launch_ranks(args.gpus))
     if args.config5:
         args.height, args.width, args.scene_views, args.fusion, args.no_planesweep = 2160, 3840, 64, True, True
         if args.gpus == 1:
@@ -310,10 +355,26 @@ def main():
     bounds = [(b * n_loc) // nb for b in range(nb + 1)]
     comm_stream = torch.cuda.Stream(device=dev)
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    full = [dict(d=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev),
-                 n=torch.empty((world, n_loc, 3 * H * W), dtype=torch.float32, device=gdev),
-                 c=torch.empty((world, n_loc, H * W), dtype=torch.float32, device=gdev)) for _ in range(nbuf)] \
+    # gathered maps, rows laid out [batch][rank][row of the batch]: the rows a batch's exchange fills are ONE
+    # contiguous block, so every exchange is one all_gather_into_tensor per map (no list of output views for
+    # the backend to assemble through a scratch buffer); with one batch per step that IS view order
+    full = [dict(d=torch.empty((world * n_loc, H * W), dtype=torch.float32, device=gdev),
+                 n=torch.empty((world * n_loc, 3 * H * W), dtype=torch.float32, device=gdev),
+                 c=torch.empty((world * n_loc, H * W), dtype=torch.float32, device=gdev)) for _ in range(nbuf)] \
         if multi else None
+    perm = None
+    if multi and nb > 1:
+        rows_of = {}
+        for b in range(nb):
+            lo, hi = bounds[b], bounds[b + 1]
+            for r in range(world):
+                for i in range(lo, hi):
+                    rows_of[r * n_loc + i] = world * lo + r * (hi - lo) + (i - lo)
+        perm = torch.tensor([rows_of[v] for v in range(world * n_loc)], dtype=torch.long, device=gdev)
+
+    def in_view_order(t):
+        """(world, n_loc, width) view / copy of a gathered map in view order"""
+        return (t if perm is None else t.index_select(0, perm)).view(world, n_loc, -1)
     fusion_inputs = None
     if args.fusion:
         # config 5: the fused, filtered cloud is part of the step (on rank 0, which like every rank
@@ -339,11 +400,12 @@ def main():
             torch.cuda.synchronize()
             out = eng.fuse_filter_views(ids, depth[k].data_ptr(), conf[k].data_ptr(), K_inv, pose_list, 3, True)
         elif backend == "nccl":
+            fd, fc = in_view_order(full[k]["d"]), in_view_order(full[k]["c"])
             torch.cuda.synchronize()
-            out = eng.fuse_filter_views(ids, full[k]["d"].data_ptr(), full[k]["c"].data_ptr(), K_inv, pose_list, 3, True)
+            out = eng.fuse_filter_views(ids, fd.data_ptr(), fc.data_ptr(), K_inv, pose_list, 3, True)
         else:
-            out = eng.fuse_filter(full[k]["d"].numpy().reshape(n_views, H, W), full[k]["c"].numpy().reshape(n_views, H, W),
-                                  cols, K_inv, pose_list, 3, True)
+            out = eng.fuse_filter(in_view_order(full[k]["d"]).numpy().reshape(n_views, H, W),
+                                  in_view_order(full[k]["c"]).numpy().reshape(n_views, H, W), cols, K_inv, pose_list, 3, True)
         state["cloud"] = out
         state["fusion_s"] += time.perf_counter() - t_f
 
@@ -367,14 +429,8 @@ def main():
                         if backend != "nccl":
                             comm_stream.synchronize()
                             inp = inp.cpu()
-                        if nb == 1:
-                            # the rank's whole block at once: straight into the (world, n_loc, width) array,
-                            # no list of output views for the backend to assemble
-                            works.append(dist.all_gather_into_tensor(full[k][name].view(world * n_loc, -1), inp,
-                                                                     async_op=True))
-                        else:
-                            outs = [full[k][name][r, lo:hi] for r in range(world)]
-                            works.append(dist.all_gather(outs, inp, async_op=True))
+                        # the batch's block of the gathered array: [rank][row of the batch], contiguous
+                        works.append(dist.all_gather_into_tensor(full[k][name][world * lo: world * hi], inp, async_op=True))
                     if backend == "nccl":
                         for w in works:
                             w.wait()                     # comm_stream (the current stream) waits, not the host
@@ -424,9 +480,8 @@ def main():
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(done)
                 if last:
-                    pairs = [(full[k]["d"].view(world * n_loc, -1), depth[k].reshape(n_loc, -1)),
-                             (full[k]["n"].view(world * n_loc, -1), normal[k].reshape(n_loc, -1)),
-                             (full[k]["c"].view(world * n_loc, -1), conf[k].reshape(n_loc, -1))]
+                    pairs = [(full[k]["d"], depth[k].reshape(n_loc, -1)), (full[k]["n"], normal[k].reshape(n_loc, -1)),
+                             (full[k]["c"], conf[k].reshape(n_loc, -1))]
                 else:
                     pairs = [(it_full[j]["d"], it_d[j]), (it_full[j]["n"], it_n[j])]
                 mine_works = []
@@ -498,12 +553,12 @@ def main():
         elapsed, first_step = float(tt[0].item()), float(tt[1].item())
         # every rank must now hold every view's maps, in view order: its own block is checked bit for
         # bit and the neighbour's block must be populated
-        fd, fc = full[k_last]["d"], full[k_last]["c"]
+        fd, fc = in_view_order(full[k_last]["d"]), in_view_order(full[k_last]["c"])
         assert torch.equal(fd[rank].to(dev), depth[k_last].reshape(n_loc, -1)), "all-gather: own depth rows differ"
         assert torch.equal(fc[rank].to(dev), conf[k_last].reshape(n_loc, -1)), "all-gather: own confidence rows differ"
         other = fd[(rank + 1) % world]
         assert float(other.min()) >= float(np.float32(sc.depth_min)) - 1e-3, "all-gather: peer rows empty"
-        assert float(full[k_last]["n"][(rank + 1) % world].abs().max()) > 0.0, "all-gather: peer normals empty"
+        assert float(in_view_order(full[k_last]["n"])[(rank + 1) % world].abs().max()) > 0.0, "all-gather: peer normals empty"
 
     n_hyp_step = (n_views if args.as_rank_of <= 0 else len(mine)) * H * W * args.iters * (2 + args.samples)
     value = n_hyp_step * args.steps / elapsed / 1e6
@@ -577,11 +632,10 @@ def main():
             t_f = time.perf_counter()
             K_inv, pose_list = np.linalg.inv(sc.camera.K), [(sc.poses[r].R, sc.poses[r].t) for r in ids]
             if backend == "nccl":
-                pts, cols, raw = eng.fuse_filter_views(ids, full[k_last]["d"].data_ptr(), full[k_last]["c"].data_ptr(),
-                                                       K_inv, pose_list, 3, True)
+                torch.cuda.synchronize()
+                pts, cols, raw = eng.fuse_filter_views(ids, fd.data_ptr(), fc.data_ptr(), K_inv, pose_list, 3, True)
             else:
-                pts, cols, raw = eng.fuse_filter(full[k_last]["d"].numpy().reshape(n_views, H, W),
-                                                 full[k_last]["c"].numpy().reshape(n_views, H, W),
+                pts, cols, raw = eng.fuse_filter(fd.numpy().reshape(n_views, H, W), fc.numpy().reshape(n_views, H, W),
                                                  np.stack([sc.colors[r] for r in ids]), K_inv, pose_list, 3, True)
             t_f = time.perf_counter() - t_f
             out["dense_points"] = {"raw": raw, "final": int(len(pts)), "fusion_inside_step": False,

@@ -343,3 +343,68 @@ def test_group_launch_plan_is_consistent_across_ranks():
                     assert gathered == list(range(len(groups))), (n, world, cap, rank, gathered)
                     seqs.append((groups, gathered))
                 assert all(s == seqs[0] for s in seqs), "ranks disagree about the collectives"
+
+
+def test_bench_starts_its_own_ranks_and_reports_a_failing_one(tmp_path):
+    """`python bench.py --gpus N` without a launcher starts N fresh child processes itself (bench.launch_ranks)
+    before anything touches torch or the GPU, relays rank 0's stdout and fails when a rank fails -- and the
+    rank that would then wait in a collective for ever is stopped.  Here (no GPU) the children are a stand-in
+    script: the launcher's environment and exit-code handling are what is under test."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "bench.py"
+    src = open(os.path.join(root, "bench.py")).read()
+    # the real launcher, a stand-in for everything after it
+    head = src[:src.index("def main():")]
+    fake.write_text(head + textwrap.dedent('''
+        def main():
+            if "WORLD_SIZE" not in os.environ:
+                sys.exit(launch_ranks(int(sys.argv[sys.argv.index("--gpus") + 1])))
+            r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+            assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+            assert int(os.environ["MASTER_PORT"]) > 0 and w == 3
+            if "--fail" in sys.argv and r == 1:
+                sys.exit(7)
+            if "--fail" in sys.argv:
+                time.sleep(60)                   # a rank stuck in a collective
+            print(json.dumps({"rank": r, "world": w}), flush=True)
+
+        main()
+    '''))
+    ok = subprocess.run([sys.executable, str(fake), "--gpus", "3"], capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0, ok.stderr
+    assert ok.stdout.strip() == '{"rank": 0, "world": 3}'          # rank 0's line only; the others went to stderr
+    assert '{"rank": 2, "world": 3}' in ok.stderr
+    import time
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, str(fake), "--gpus", "3", "--fail"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 7 and time.time() - t0 < 30, (bad.returncode, bad.stderr)
+    assert "rank 1 exited with 7" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_self_launched_on_one_gpu():
+    """The driver's command shape, `python bench.py --gpus 2 ...` with no launcher and no WORLD_SIZE, on a
+    one-GPU box: both ranks on cuda:0, the exchange over gloo (AMVS_BENCH_BACKEND / AMVS_BENCH_ONE_DEVICE
+    are rehearsal switches; the real run is one rank per GPU over RCCL).  One valid JSON line, the strong-
+    scaling scene, two batches per step with their contiguous all_gather_into_tensor blocks, and the
+    bench's own closing asserts (own rows bit for bit, peer rows populated)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMVS_BENCH_BACKEND="gloo", AMVS_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--scene-views", "16", "--height", "270", "--width", "480", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["views_per_gpu"] == 8 and rec["config"]["batches_per_step"] == 2
+    assert rec["value"] > 0 and rec["dense_points"]["raw"] > 0

@@ -208,14 +208,13 @@ def test_strip_orders_give_identical_maps(mode):
             p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule=schedule)
             maps[schedule] = eng.patchmatch(ids, sources, p, 11)
             rows[schedule] = eng.last_tile_rows()
-        if mode == "fast":
-            # paired bands with an even band count whose last band is short (540 = 33 x 16 + 12), an odd one
-            # (27 bands of 20 rows: the last band has no partner) and single-band strips (one band of 540)
-            for tr in (16, 20, 540):
-                p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule="paired", tile_rows=tr)
-                maps[f"paired/{tr}"] = eng.patchmatch(ids, sources, p, 11)
+        # paired bands (both arithmetic modes have their own PAIR kernel) with an even band count whose last band
+        # is short (540 = 33 x 16 + 12), an odd one (27 bands of 20 rows: the last band has no partner) and
+        # single-band strips (one band of 540)
+        for tr in (16, 20, 540):
+            p = make_pm_params(7, 2, 3, sc.depth_min, sc.depth_max, schedule="paired", tile_rows=tr)
+            maps[f"paired/{tr}"] = eng.patchmatch(ids, sources, p, 11)
     assert rows["band-major"] != rows["view-major"], rows          # a different launch shape was really used
-    # (the paired-band schedule exists in the fast arithmetic; in exact it runs as view-major)
     for schedule in maps:
         for a, b, what in zip(maps["view-major"], maps[schedule], ("depth", "normal", "confidence")):
             _eq(b, a, f"{mode} {schedule} {what}")
@@ -257,6 +256,45 @@ def test_sweep_continued_one_iteration_per_call(scene_a, mode, entry):
             run(eng, n=1, first_iteration=1)                     # 3 iterations were run, not 1
         with pytest.raises(amvs.AmvsError):
             eng.patchmatch([2], [[1, 3, 0, 4]], make_pm_params(7, 1, samples, sc.depth_min, sc.depth_max, first_iteration=3), 9)
+
+
+def test_state_invalidation_flags_and_stale_step_times(scene_a):
+    """ADVICE (round 3).  (1) The host plane sweep writes its maps into slot 0 of the PatchMatch state: a
+    continuation after it is refused.  (2) AMVS_PM_NO_CONFIDENCE leaves the caller's confidence array
+    untouched (host entry point, fused and split schedules).  (3) amvs_get_step_times after a call that
+    records no per-launch events (plane sweep, split schedule) returns none instead of stale intervals."""
+    import amvs
+    from amvs.engine import make_pm_params
+    sc = scene_a
+    refs, srcs = [2], [[1, 3, 0, 4]]
+    depths = (1.0 / np.linspace(1 / sc.depth_max, 1 / sc.depth_min, 8)).astype(np.float32)
+    with sc.engine("fast") as eng:
+        eng.set_step_timing(True)
+        p1 = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max, confidence=False)
+        d, n, c = eng.patchmatch(refs, srcs, p1, 9)
+        assert len(eng.step_times()) == 4                       # 2 propagation + 2 refinement launches
+        # (2) the confidence array comes back as numpy allocated it: fill it through the binding by hand
+        import ctypes as C
+        from amvs._lib import f32p, i32p
+        conf = np.full((1, sc.H, sc.W), -7.0, np.float32)
+        dd = np.empty((1, sc.H, sc.W), np.float32)
+        nn = np.empty((1, sc.H, sc.W, 3), np.float32)
+        ref = np.asarray(refs, np.int32)
+        src = np.asarray(srcs, np.int32)
+        for schedule in ("auto", "split"):
+            p = make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max, confidence=False, schedule=schedule)
+            rc = eng._lib.amvs_patchmatch(eng._h, 1, ref.ctypes.data_as(i32p), src.ctypes.data_as(i32p), 4, C.byref(p), 9,
+                                          dd.ctypes.data_as(f32p), nn.ctypes.data_as(f32p), conf.ctypes.data_as(f32p))
+            assert rc == 0 and np.all(conf == -7.0), schedule
+            assert np.array_equal(dd[0], d[0]), schedule
+        assert len(eng.step_times()) == 0                       # (3) the split schedule records none
+        eng.patchmatch(refs, srcs, p1, 9)
+        assert len(eng.step_times()) == 4
+        # (1), (3): the plane sweep lands in slot 0 and records no step events
+        eng.plane_sweep(2, [1, 3, 0, 4], depths, 5, 0.8)
+        assert len(eng.step_times()) == 0
+        with pytest.raises(amvs.AmvsError):
+            eng.patchmatch(refs, srcs, make_pm_params(7, 1, 2, sc.depth_min, sc.depth_max, first_iteration=1), 9)
 
 
 def test_native_rccl_entry_points_single_rank():

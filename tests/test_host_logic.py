@@ -292,3 +292,21 @@ def test_extended_restatement_is_sane_on_the_cpu():
     assert np.array_equal(D[~swept], start[~swept]) and np.isinf(C[~swept]).all()
     got = swept & np.isfinite(C)
     assert got.mean() > 0.25 and np.median(np.abs(D[got] - gt[got]) / gt[got]) < 0.01
+
+
+def test_native_exchange_without_rccl_is_unsupported_not_fatal():
+    """ADVICE (round 3): when librccl cannot be opened, amvs_comm_unique_id / amvs_comm_init return
+    AMVS_EUNSUPPORTED with a message, as include/amvs.h documents (the first version built the message from
+    two dlerror() calls, the second of which returns NULL).  AMVS_RCCL_LIB names the library to open; a
+    fresh process, because the lookup happens once per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); import amvs; from amvs import _lib; L = _lib.load();"
+            "buf = (C.c_uint8 * 128)(); rc = L.amvs_comm_unique_id(buf); print(rc); print(L.amvs_last_error(None).decode());"
+            "rc2 = L.amvs_comm_unique_id(buf); print(rc2)") % ROOT
+    env = dict(os.environ, AMVS_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert lines[0] == "-3" and lines[-1] == "-3", out.stdout          # AMVS_EUNSUPPORTED, twice
+    assert "RCCL not found" in lines[1] and "/nonexistent/librccl.so.1" in lines[1]
