@@ -135,7 +135,7 @@ int check_patch_src(amvs_ctx *c, int patch, int n_src)
 {
     if (!amvs::patch_supported(patch))
         return fail(c, AMVS_EUNSUPPORTED,
-                    "patch_size " + std::to_string(patch) + " not compiled in (supported: 3, 5, 7, 9, 11)");
+                    "patch_size " + std::to_string(patch) + " unsupported (odd sizes from 3 to " + std::to_string(AMVS_MAX_PATCH) + ")");
     if (n_src < 2 || n_src > AMVS_MAX_SRC)
         return fail(c, AMVS_EUNSUPPORTED,
                     "n_src " + std::to_string(n_src) + " outside [2, " + std::to_string(AMVS_MAX_SRC) + "]");
@@ -1703,7 +1703,7 @@ int amvs_box_stats(amvs_ctx *c, int view, int patch_size, float *mean_out, float
         return fail(c, AMVS_EINVAL, "bad view / NULL output");
     int rc = bind_device(c);
     if (rc) return rc;
-    if (!amvs::patch_supported(patch_size)) return fail(c, AMVS_EUNSUPPORTED, "patch_size not compiled in");
+    if (!amvs::patch_supported(patch_size)) return fail(c, AMVS_EUNSUPPORTED, "patch_size unsupported (odd sizes from 3 to 31)");
     if ((rc = ensure_stats(c, patch_size))) return rc;
     const Stats &s = c->stats.at(patch_size);
     const size_t hw = (size_t)c->H * c->W;

@@ -6,6 +6,7 @@
 #define AMVS_KMAX_SRC 6
 #define AMVS_SWEEP_MAX_TH 32
 #define AMVS_SWEEP_MAX_CHUNK 4096     // planes one wave sweeps (12-bit plane index in its LDS keys)
+#define AMVS_MAX_PATCH 31             // largest (odd) patch size: the run-time-k kernels' rings fit 64 KB of LDS up to here
 
 namespace amvs {
 
@@ -110,7 +111,18 @@ struct SweepArgs : StepArgsBase {
     const Job *jobs;
 };
 
-bool patch_supported(int K);
+bool patch_supported(int K);          // any odd patch size in 3 .. AMVS_MAX_PATCH
+bool patch_compiled(int K);           // ... with kernels specialised at compile time (3, 5, 7, 9, 11); the others run
+                                      // the run-time-k kernels of amvs_generic.hip
+// amvs_generic.hip: sweep step / plane sweep / statistics with the patch size as a launch argument (both
+// arithmetic modes, classic schedule); launch_step / launch_sweep / launch_box_stats / launch_fast_stats forward
+// to these for patch sizes that are not compiled in
+hipError_t launch_step_generic(int K, int S, const StepArgs &a, hipStream_t st);
+hipError_t launch_sweep_generic(int K, int S, const SweepArgs &a, hipStream_t st);
+hipError_t launch_box_stats_generic(int K, const float *images, long long img_stride, int H, int W, int first_img, int n_img,
+                                    float *mean_out, float *var_out, hipStream_t st);
+hipError_t launch_fast_stats_generic(int K, const uint16_t *pairs_view, int H, int W, float2 *out, hipStream_t st);
+int step_generic_waves_per_cu(int K, int S);
 bool knn_supported(int k);
 hipError_t knn_mean_distance(const double *points, long long n, int k, double *mean_out, hipStream_t st,
                              bool points_on_device = false);

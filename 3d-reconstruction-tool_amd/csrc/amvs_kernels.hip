@@ -17,101 +17,9 @@
 //     buffers "in" and writes buffers "out", so strips never see half-updated maps.
 //   * block index -> strip mapping is XCD-aware: each of the 8 XCDs receives a contiguous
 //     range of strips so halos and source-image rows are shared in that XCD's L2.
-#include "amvs_kernel_common.h"
+#include "amvs_exact_common.h"
 
 namespace amvs {
-
-// Where pm_step tests the validity of its lean reciprocals / square roots: once per row and stage
-// (1) or after every operation / source (0, measured 2 % faster there).  The plane sweep always
-// uses the per-row form (+3 %).  AMVS_RELOAD_STRIDE sources share one opaque pointer copy (which
-// is also a scheduling barrier), so their arithmetic can interleave; 1 is fastest (registers).
-// (Sampling the sources two at a time with packed fp32 arithmetic -- v_pk_fma/mul/add_f32 on pose
-// pairs interleaved in the job table, 5 % fewer VALU instructions, bit-identical -- was measured
-// 1-2 % slower in three different states of this kernel and is no longer carried in the source.)
-#ifndef AMVS_RELOAD_STRIDE
-#define AMVS_RELOAD_STRIDE 1
-#endif
-#ifndef AMVS_PM_ROW_CHECK_SAMPLING
-#define AMVS_PM_ROW_CHECK_SAMPLING 0
-#endif
-#ifndef AMVS_PM_ROW_CHECK_NCC
-#define AMVS_PM_ROW_CHECK_NCC 0
-#endif
-
-// The scalar operands of one source: one 64-byte record of the job table (SrcEntry), i.e. one
-// batch of scalar loads and one wait.
-struct SrcScalars { float R[9], t[3]; unsigned long long img; };
-AMVS_DEV SrcScalars load_src_scalars(JobCP jr, int s, bool u8)
-{
-    SrcScalars c;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) c.R[i] = jr->src[s].R[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) c.t[i] = jr->src[s].t[i];
-    c.img = u8 ? jr->src[s].pairs : jr->src[s].gray;
-    return c;
-}
-
-#ifndef AMVS_STEP_PRIO
-#define AMVS_STEP_PRIO true
-#endif
-// Sample all S sources of one pixel.
-// LEAN / `ok`: optimistic lean reciprocal (amvs_device.h).  SRC_CHECK = true tests `ok` after each
-// source's geometry and repeats that geometry with IEEE arithmetic (one wave-uniform branch per
-// source); SRC_CHECK = false leaves the test to the caller (one branch per row).
-// PRIO (the sweep step): raised issue priority from here until the gathers are requested -- see
-// fast_sample_sources (amvs_kernels_fast.hip).
-template <int S, bool U8, bool LEAN, bool SRC_CHECK, bool PRIO = false>
-AMVS_DEV unsigned sample_sources(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                 Vec3 Pw, bool live, float (&v)[S], bool &ok)
-{
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-    unsigned okbits = 0u;
-    JobCP jr = job;
-    // the shared intrinsics: loaded once per row, with the reference pose (same scalar-load batch)
-    float Kc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Kc[i] = jr->K[i];
-    // Geometry of every source first, each gather issued as soon as its address exists, then the
-    // decodes: the S gather latencies overlap (one exposed wait per row instead of S: +3 %).  The
-    // taps' weights wait in registers meanwhile (4 per source) -- affordable since the window-sum
-    // stage, not the sampling stage, sets this kernel's register peak.
-    TapGeom<U8> tg[S];
-    TapRaw<U8> tr[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        bool valid;
-        if (s % AMVS_RELOAD_STRIDE == 0) jr = reload(jr);
-        const SrcScalars c = load_src_scalars(jr, s, U8);
-        if constexpr (SRC_CHECK) {
-            bool ok_s = true;
-            tg[s] = sample_geom<U8, true>(Kc, c.R, c.t, sc, Pw, live, valid, ok_s);
-            if (__builtin_expect(!__all(ok_s), 0)) tg[s] = sample_geom<U8, false>(Kc, c.R, c.t, sc, Pw, live, valid, ok_s);
-        } else {
-            tg[s] = sample_geom<U8, LEAN>(Kc, c.R, c.t, sc, Pw, live, valid, ok);
-        }
-        okbits |= valid ? (1u << s) : 0u;
-        tr[s] = sample_load<U8>(c.img, tg[s], sc.W + 2 * AMVS_PAIR_BORDER);
-    }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int s = 0; s < S; ++s) v[s] = sample_finish<U8>(tr[s], tg[s], lut, live);
-    return okbits;
-}
-
-// Optimistic sampling of a row: lean arithmetic first; the IEEE repeat only when some lane's
-// projection depth left the range the lean reciprocal is verified for (amvs_device.h).
-template <int S, bool U8, bool ROW_CHECK, bool PRIO = false>
-AMVS_DEV unsigned sample_sources_checked(JobCP job, const StepArgsBase &a, const SampleConsts &sc, const float *lut,
-                                         Vec3 Pw, bool live, float (&v)[S])
-{
-    bool ok = true;
-    if constexpr (!ROW_CHECK) return sample_sources<S, U8, true, true, PRIO>(job, a, sc, lut, Pw, live, v, ok);
-    unsigned okbits = sample_sources<S, U8, true, false, PRIO>(job, a, sc, lut, Pw, live, v, ok);
-    if (__builtin_expect(!__all(ok), 0))
-        okbits = sample_sources<S, U8, false, false, PRIO>(reload(job), a, sc, lut, Pw, live, v, ok);
-    return okbits;
-}
 
 // ------------------------------------------------------------------ window sums --
 // k x k window sums of v, v*v and r*v for S sources at once, from the per-lane vertical rings.
@@ -1122,16 +1030,18 @@ int step_waves_per_cu(int K, int S, bool u8, int wg_cap)
     case 7: AMVS_FOR_S(7, step_occupancy_ks, u8, wg_cap)
     case 9: AMVS_FOR_S(9, step_occupancy_ks, u8, wg_cap)
     case 11: AMVS_FOR_S(11, step_occupancy_ks, u8, wg_cap)
-    default: return 8;
+    default: return step_generic_waves_per_cu(K, S);
     }
 }
 
-bool patch_supported(int K) { return K == 3 || K == 5 || K == 7 || K == 9 || K == 11; }
-bool step_pair_supported(int K, int S) { return patch_supported(K) && S >= 2 && S <= AMVS_KMAX_SRC && step_pair_supported_ks(K, S); }
+bool patch_compiled(int K) { return K == 3 || K == 5 || K == 7 || K == 9 || K == 11; }
+bool patch_supported(int K) { return K >= 3 && K <= AMVS_MAX_PATCH && (K & 1) == 1; }
+bool step_pair_supported(int K, int S) { return patch_compiled(K) && S >= 2 && S <= AMVS_KMAX_SRC && step_pair_supported_ks(K, S); }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
 
 hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 {
+    if (!patch_compiled(K)) return launch_step_generic(K, S, a, st);
     if (a.fast) return launch_step_fast(K, S, a, st);
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y;
     switch (K) {
@@ -1146,6 +1056,7 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
 
 hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
 {
+    if (!patch_compiled(K)) return launch_sweep_generic(K, S, a, st);
     if (a.fast) return launch_sweep_fast(K, S, a, st);
     const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
     switch (K) {
@@ -1171,6 +1082,7 @@ hipError_t launch_box_stats(int K, const float *images, long long img_stride, in
                             int first_img, int n_img, float *mean_out, float *var_out,
                             hipStream_t st)
 {
+    if (!patch_compiled(K)) return launch_box_stats_generic(K, images, img_stride, H, W, first_img, n_img, mean_out, var_out, st);
     const int TH = 32;
     const int tiles_x = (W + strip_out_width(K) - 1) / strip_out_width(K);
     const int tiles_y = (H + TH - 1) / TH;

@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void fast_stats_kernel(const uint16_t *__restr
 
 hipError_t launch_fast_stats(int K, const uint16_t *pairs_view, int H, int W, float2 *out, hipStream_t st)
 {
+    if (!patch_compiled(K)) return launch_fast_stats_generic(K, pairs_view, H, W, out, st);
     const long long n = (long long)H * W;
     const dim3 grid((unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), blk(256);
     switch (K) {
@@ -586,11 +587,11 @@ int step_fast_waves_per_cu(int K, int S, int wg_cap)
     case 7: AMVS_FOR_S(7, step_fast_occupancy_ks, wg_cap)
     case 9: AMVS_FOR_S(9, step_fast_occupancy_ks, wg_cap)
     case 11: AMVS_FOR_S(11, step_fast_occupancy_ks, wg_cap)
-    default: return 8;
+    default: return step_generic_waves_per_cu(K, S);
     }
 }
 
-bool step_fast_pair_supported(int K, int S) { return patch_supported(K) && S >= 2 && S <= AMVS_KMAX_SRC && fast_pair_supported(K, S); }
+bool step_fast_pair_supported(int K, int S) { return patch_compiled(K) && S >= 2 && S <= AMVS_KMAX_SRC && fast_pair_supported(K, S); }
 
 hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
 {

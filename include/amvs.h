@@ -32,7 +32,7 @@ extern "C" {
 #define AMVS_OK            0
 #define AMVS_EINVAL       -1   /* bad argument                                  */
 #define AMVS_EHIP         -2   /* HIP runtime error (no device, OOM, launch)    */
-#define AMVS_EUNSUPPORTED -3   /* patch size / source count not compiled in     */
+#define AMVS_EUNSUPPORTED -3   /* patch size (even, or above 31) / source count outside [2, 6] / k of the kNN */
 
 typedef struct amvs_ctx amvs_ctx;
 
@@ -57,7 +57,9 @@ typedef struct amvs_ctx amvs_ctx;
  * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
  * and (float)ln dmin formed in double by the host, as :268-271 does.           */
 typedef struct {
-    int32_t patch_size;       /* odd; compiled: 3, 5, 7, 9, 11                         */
+    int32_t patch_size;       /* any odd size in 3..31 (mvs_patchmatch.py:45 takes any); 3, 5, 7, 9, 11 run
+                                 kernels specialised at compile time, the others the run-time-k kernels
+                                 (csrc/amvs_generic.hip: same results contract, classic schedule, slower)  */
     int32_t num_iterations;
     int32_t num_samples;
     int32_t tile_rows;        /* rows per wave strip; 0 = choose automatically    */

@@ -1,0 +1,224 @@
+"""Any odd patch size (round 4): the run-time-k kernels of csrc/amvs_generic.hip against the CPU oracle, whose k is
+a run-time argument and which tests/test_oracle_modes_golden.py pins at k = 13, 15 against the reference's own
+outputs (g19, g20, g21).  The reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36,
+:325-341); the compiled kernels cover 3, 5, 7, 9, 11, every other odd size up to 31 runs here.
+
+Bar: BIT-EXACT against the oracle in both arithmetic modes; the reference tolerances of tests/conftest.py against
+the goldens.
+"""
+import numpy as np
+import pytest
+
+from conftest import CONF_HIST_TOL, E2E_MIN_FRACTION, assert_cost_close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+MODES = ("exact", "fast")
+
+
+def _eq(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    assert same.all(), f"{what}: {int((~same).sum())} of {same.size} elements differ " \
+                       f"(first at {np.argwhere(~same)[0]}: {a[~same][0]!r} vs {b[~same][0]!r})"
+
+
+@pytest.fixture(scope="module", params=MODES)
+def eng_mode(request, scene_a):
+    eng = scene_a.engine(request.param)
+    yield eng, request.param
+    eng.close()
+
+
+def _mixed_depth(scene, ref, seed):
+    rng = np.random.default_rng(seed)
+    d = np.exp(rng.uniform(np.log(scene.depth_min), np.log(scene.depth_max), (scene.H, scene.W))).astype(np.float32)
+    d[:, scene.W // 2:] = scene.gt_depth[ref][:, scene.W // 2:]
+    d[:5, :7] = np.float32(0.05)
+    d[-6:, -9:] = np.float32(400.0)
+    return d
+
+
+@pytest.mark.parametrize("k", [13, 15, 21, 31])
+def test_box_stats_bit_exact(scene_a, k):
+    from oracle import oracle
+    with scene_a.engine() as eng:
+        for v in (0, 3):
+            m, var = eng.box_stats(v, k)
+            om, ovar = oracle.box_stats(scene_a.grays[v], k)
+            _eq(m, om, f"mean k{k}")
+            _eq(var, ovar, f"var k{k}")
+
+
+@pytest.mark.parametrize("k", [13, 15, 17, 23, 31])
+@pytest.mark.parametrize("srcs", [[1, 3, 0, 4], [3, 1], [0, 1, 4]])
+def test_eval_cost_bit_exact(eng_mode, scene_a, k, srcs):
+    eng, mode = eng_mode
+    ref = 2
+    depth = _mixed_depth(scene_a, ref, 5)
+    got = eng.eval_cost(ref, srcs, k, depth)
+    want = scene_a.oracle_ctx(ref, srcs, k, mode).patch_cost(depth)
+    assert np.isfinite(want).any()
+    _eq(got, want, f"{mode} cost k{k} S{len(srcs)}")
+
+
+def test_eval_cost_vs_reference_golden(eng_mode):
+    eng, mode = eng_mode
+    g = load_golden("g19_patch_cost_k13_15")
+    for k in (13, 15):
+        got = eng.eval_cost(int(g["ref"]), list(g["srcs"]), k, g["depth"])
+        if mode == "exact":
+            assert_cost_close(got, g[f"cost_k{k}"], 1e-4, f"k{k}")
+        else:
+            fin = np.isfinite(got) & np.isfinite(g[f"cost_k{k}"])
+            assert (np.isfinite(got) != np.isfinite(g[f"cost_k{k}"])).sum() <= 3
+            assert np.quantile(np.abs(got - g[f"cost_k{k}"])[fin], 0.999) < 1e-4
+
+
+def test_confidence_bit_exact(eng_mode, scene_a):
+    eng, mode = eng_mode
+    g = load_golden("g07_confidence")
+    ref, srcs = int(g["ref"]), list(g["srcs"])
+    for k in (13, 19):
+        got = eng.confidence(ref, srcs, k, g["depth"])
+        _eq(got, scene_a.oracle_ctx(ref, srcs, k, mode).confidence(g["depth"]), f"{mode} confidence k{k}")
+
+
+@pytest.mark.parametrize("off", [(1, 0), (0, 1), (-1, 0), (0, -1)])
+def test_propagate_step_bit_exact(eng_mode, scene_a, off):
+    eng, mode = eng_mode
+    g = load_golden("g04_propagate")
+    ref, srcs, k = int(g["ref"]), list(g["srcs"]), 13
+    # (g04's cost map belongs to another patch size: a first evaluation gives this patch's costs)
+    cost = scene_a.oracle_ctx(ref, srcs, k, mode).patch_cost(g["depth"])
+    got = eng.propagate_step(ref, srcs, k, g["depth"], g["normal"], cost, off[0], off[1], scene_a.depth_min)
+    want = scene_a.oracle_ctx(ref, srcs, k, mode).propagate_step(g["depth"], g["normal"], cost, off[0], off[1],
+                                                                 scene_a.depth_min)
+    for a, b, name in zip(got, want, ("depth", "normal", "cost")):
+        _eq(a, b, f"{mode} propagate {off} {name}")
+    assert (got[0] != g["depth"]).mean() > 0.01
+
+
+@pytest.mark.parametrize("it", [0, 2])
+def test_refine_step_bit_exact(eng_mode, scene_a, it):
+    from oracle import oracle
+    eng, mode = eng_mode
+    g = load_golden("g05_refine")
+    ref, srcs, k, seed = int(g["ref"]), list(g["srcs"]), 15, int(g["seed"])
+    dr = np.float32((scene_a.depth_max - scene_a.depth_min) * 0.5 ** it)
+    nr = np.float32(0.5 * 0.5 ** it)
+    ctx = scene_a.oracle_ctx(ref, srcs, k, mode)
+    d, n = g["depth"], g["normal"]
+    c = ctx.patch_cost(d)
+    od, on, oc = d, n, c
+    for s in range(2):
+        draw = 1 + it * 2 + s
+        d, n, c = eng.refine_step(ref, srcs, k, d, n, c, seed, ref, draw, dr, nr, scene_a.depth_min, scene_a.depth_max)
+        u, nz = oracle.rng_fill(seed, ref, draw, scene_a.H * scene_a.W)
+        od, on, oc = ctx.refine_step(od, on, oc, u, nz, dr, nr, scene_a.depth_min, scene_a.depth_max)
+        _eq(d, od, f"{mode} refine it{it} s{s} depth")
+        _eq(c, oc, f"{mode} refine it{it} s{s} cost")
+        _eq(n, on, f"{mode} refine it{it} s{s} normal")
+    assert (d != g["depth"]).mean() > 0.005
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_patchmatch_k13_bit_exact_and_reference_golden(scene_d, mode):
+    """_patchmatch_cuda with a 13x13 patch (g20): bit-exact against the oracle, within the reference tolerances
+    against the reference's own maps; two views in one batch, several strips per view (tile_rows)."""
+    from amvs.engine import make_pm_params
+    g = load_golden("g20_patchmatch_k13")
+    r, srcs, k = int(g["ref"]), list(g["srcs"]), int(g["patch"])
+    with scene_d.engine(mode) as eng:
+        p = make_pm_params(k, int(g["iters"]), int(g["samples"]), scene_d.depth_min, scene_d.depth_max)
+        depth, normal, conf = eng.patchmatch([r, 1], [srcs, [0, 2, 3, 4]], p, int(g["seed"]))
+        assert eng.timing()["sweep_launches"] == 3 * (2 + 4)
+        p2 = make_pm_params(k, int(g["iters"]), int(g["samples"]), scene_d.depth_min, scene_d.depth_max, tile_rows=9)
+        depth2, normal2, conf2 = eng.patchmatch([r], [srcs], p2, int(g["seed"]))
+    for i, (view, ss) in enumerate(((r, srcs), (1, [0, 2, 3, 4]))):
+        od, on, oc = scene_d.oracle_ctx(view, ss, k, mode).patchmatch(int(g["iters"]), int(g["samples"]), scene_d.depth_min,
+                                                                      scene_d.depth_max, int(g["seed"]), view)
+        _eq(depth[i], od, f"{mode} view {view} depth")
+        _eq(conf[i], oc, f"{mode} view {view} confidence")
+        _eq(normal[i], on, f"{mode} view {view} normal")
+    _eq(depth2[0], depth[0], f"{mode} 9-row strips depth")
+    _eq(normal2[0], normal[0], f"{mode} 9-row strips normal")
+    _eq(conf2[0], conf[0], f"{mode} 9-row strips confidence")
+    rel = np.abs(depth[0] - g["depth"]) / g["depth"]
+    assert np.mean(rel <= 1e-3) >= E2E_MIN_FRACTION
+    hist_got = np.bincount(conf[0].astype(int).ravel(), minlength=5) / conf[0].size
+    hist_ref = np.bincount(g["confidence"].astype(int).ravel(), minlength=5) / conf[0].size
+    assert np.abs(hist_got - hist_ref).max() < CONF_HIST_TOL
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_plane_sweep_k13_bit_exact_and_reference_golden(scene_d, mode):
+    g = load_golden("g21_plane_sweep_k13")
+    ref, nbrs, k = int(g["ref"]), list(g["nbrs"]), int(g["patch"])
+    depths = g["depths"].astype(np.float32)
+    with scene_d.engine(mode) as eng:
+        d, conf = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
+        eng.set_sweep_tuning(tile_rows=5, planes_per_wave=3)              # several strips, several plane chunks
+        d2, conf2 = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
+        d3, conf3 = eng.plane_sweep(ref, nbrs[:3], depths, 17, -0.2)       # the division form of the fast vote
+    od, oc = scene_d.oracle_ctx(ref, nbrs, k, mode).plane_sweep(depths, float(g["thresh"]))
+    _eq(d, od, f"{mode} depth")
+    _eq(conf, oc, f"{mode} confidence")
+    _eq(d2, od, f"{mode} depth (chunked)")
+    _eq(conf2, oc, f"{mode} confidence (chunked)")
+    od3, oc3 = scene_d.oracle_ctx(ref, nbrs[:3], 17, mode).plane_sweep(depths, -0.2)
+    _eq(d3, od3, f"{mode} k17 depth")
+    _eq(conf3, oc3, f"{mode} k17 confidence")
+    assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
+
+
+@pytest.mark.parametrize("shape,k,S", [((33, 59), 13, 3), ((70, 117), 15, 3), ((41, 200), 25, 2), ((20, 64), 31, 3)])
+def test_ragged_shapes_and_float_images_bit_exact(shape, k, S):
+    """Widths that are not multiples of the strip's output width (64 - 2 (k/2)), heights below the patch size, and
+    rendered float images (not 8-bit exact: the exact arithmetic samples the float32 maps, U8 = false)."""
+    import amvs
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    H, W = shape
+    sc = make_scene(4, H, W, seed=H)
+    K = sc.camera.K.astype(np.float32)
+    others = [0, 2, 3][:S]
+    for quantise in (False, True):
+        grays = [(np.round(g * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0) if quantise else g
+                 for g in sc.grays]
+        with amvs.Engine(H, W, 4, K) as eng:
+            for i in range(4):
+                eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+            assert eng.sampling_mode() == ("u8-pairs" if quantise else "f32")
+            p = make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max)
+            depth, normal, conf = eng.patchmatch([1], [others], p, 9)
+        ctx = oracle.ViewContext(K, grays[1], sc.poses[1].R, sc.poses[1].t, [grays[i] for i in others],
+                                 [sc.poses[i].R for i in others], [sc.poses[i].t for i in others], k)
+        od, on, oc = ctx.patchmatch(2, 2, sc.depth_min, sc.depth_max, 9, 1)
+        _eq(depth[0], od, f"{shape} k{k} depth (8-bit {quantise})")
+        _eq(conf[0], oc, f"{shape} k{k} conf (8-bit {quantise})")
+        _eq(normal[0], on, f"{shape} k{k} normal (8-bit {quantise})")
+
+
+def test_classes_accept_any_odd_patch_size(scene_b, capsys):
+    """PatchMatchMVS(patch_size=13) / DenseStereoReconstructor(patch_size=13) run end to end (the reference's
+    constructors take any patch size); even and oversized patches are refused with a message."""
+    import amvs
+    from amvs._lib import AmvsError
+    cam = amvs.Camera(K=scene_b.K.copy(), dist=np.zeros(5))
+    images = [{"image": c} for c in scene_b.colors]
+    pm = amvs.PatchMatchMVS(cam, scale=1.0, patch_size=13, num_iterations=2, num_samples=2, min_views=2,
+                            depth_min=scene_b.depth_min, depth_max=scene_b.depth_max, seed=3)
+    pm._estimate_depth_range = lambda poses, pts=None: None           # keep the scene's own range
+    pts, cols = pm.reconstruct(images, scene_b.poses())
+    assert pts.ndim == 2 and pts.shape[1] == 3 and len(pts) == len(cols)
+    ds = amvs.DenseStereoReconstructor(cam, scale=1.0, num_depths=8, patch_size=13, min_views=2)
+    pts2, cols2 = ds.reconstruct(images, scene_b.poses())
+    assert pts2.ndim == 2 and len(pts2) == len(cols2)
+    capsys.readouterr()
+    with scene_b.engine() as eng:
+        for bad in (6, 33, 1):
+            with pytest.raises(AmvsError, match="patch_size"):
+                eng.eval_cost(1, [0, 2], bad, scene_b.gt_depth[1])

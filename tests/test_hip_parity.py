@@ -660,7 +660,7 @@ def test_error_paths(eng_a, scene_a, amvs_mod):
     from amvs._lib import AmvsError
     d = scene_a.gt_depth[2]
     with pytest.raises(AmvsError, match="patch_size"):
-        eng_a.eval_cost(2, [1, 3], 13, d)
+        eng_a.eval_cost(2, [1, 3], 33, d)              # (odd sizes up to 31 run: tests/test_hip_generic_patch.py)
     with pytest.raises(AmvsError, match="patch_size"):
         eng_a.eval_cost(2, [1, 3], 6, d)
     with pytest.raises(AmvsError, match="n_src"):

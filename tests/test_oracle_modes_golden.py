@@ -188,3 +188,32 @@ def test_fast_mode_needs_8bit_images():
                              [np.eye(3)] * 2, [np.zeros(3)] * 2, 3)
     with pytest.raises(ValueError, match="8-bit"):
         ctx.set_mode("fast")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_large_patch_sizes_against_the_reference(scene_a, scene_d, mode):
+    """Round 4: the reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36);
+    the oracle's k is a run-time argument.  Pinned here for the sizes that run on the run-time-k kernels
+    (csrc/amvs_generic.hip): _compute_patch_cost at k = 13, 15 (g19), _patchmatch_cuda at k = 13 (g20),
+    _plane_sweep_torch at k = 13 (g21) -- captured from the reference by tests/golden/make_golden_r4.py."""
+    g = load_golden("g19_patch_cost_k13_15")
+    ref, srcs = int(g["ref"]), list(g["srcs"])
+    for k in (13, 15):
+        got = scene_a.oracle_ctx(ref, srcs, k, mode).patch_cost(g["depth"])
+        flips, err = _cost_stats(got, g[f"cost_k{k}"])
+        big = int((err > 1e-4).sum())
+        if mode == "exact":
+            assert flips == 0 and big == 0, f"k{k}: {flips} validity flips, {big} errors > 1e-4"
+            assert err.mean() < 5e-6
+        else:
+            assert flips + big <= 3, f"k{k}: {flips} validity flips + {big} large errors (knife-edge pixels)"
+            assert np.quantile(err, 0.999) < 1e-4 and np.median(err) < 5e-6
+    g = load_golden("g20_patchmatch_k13")
+    r = int(g["ref"])
+    ctx = scene_d.oracle_ctx(r, list(g["srcs"]), int(g["patch"]), mode)
+    d, n, conf = ctx.patchmatch(int(g["iters"]), int(g["samples"]), scene_d.depth_min, scene_d.depth_max, int(g["seed"]), r)
+    _e2e_check(d, conf, g["depth"], g["confidence"], f"g20 k=13 ({mode})")
+    g = load_golden("g21_plane_sweep_k13")
+    ctx = scene_d.oracle_ctx(int(g["ref"]), list(g["nbrs"]), int(g["patch"]), mode)
+    d, conf = ctx.plane_sweep(g["depths"].astype(np.float32), float(g["thresh"]))
+    assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
