@@ -1250,6 +1250,12 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     a.fast = fast;
     a.depths = c->d_planes;
     a.thresh = thresh;
+    if (!fast && amvs::patch_compiled(patch_size)) {
+        // the exact sweep loads the reference views' window statistics (plane-invariant) from the resident maps
+        if ((rc = ensure_stats(c, patch_size))) return rc;
+        a.ref_mean = c->stats[patch_size].mean;
+        a.ref_var = c->stats[patch_size].var;
+    }
     a.depth_out = (float *)depth_dev; a.conf_out = (float *)conf_dev;
     a.keys = c->d_keys;
     a.jobs = c->d_jobs;

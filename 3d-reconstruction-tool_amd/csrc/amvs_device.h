@@ -343,21 +343,35 @@ template <bool U8> struct TapRaw;
 template <> struct TapRaw<true> { uint32_t w; };
 template <> struct TapRaw<false> { float t00, t01, t10, t11; };
 
-template <bool U8, bool LEAN, class KP, class RP, class TP>
+// NOBOUNDS (the plane sweep: lo = -inf, hix = hiy = +inf, dense_stereo.py:280,303 tests z only): the four bound
+//          comparisons collapse to u < +inf, v < +inf (false exactly for NaN and +inf, as the four are).
+// TRACK    (with LEAN): instead of testing every reciprocal's operand (`ok`), collect min / max |z + 1e-8| in
+//          *zlo / *zhi; the caller tests the range once per row (the same condition, fewer instructions).
+template <bool U8, bool LEAN, bool NOBOUNDS = false, bool TRACK = false, class KP, class RP, class TP>
 AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3 Pw, bool live, bool &valid,
-                                 bool &ok)
+                                 bool &ok, float *zlo = nullptr, float *zhi = nullptr)
 {
     const int H = c.H, W = c.W;
     float p0 = __builtin_fmaf(Pw.z, Rs[2], __builtin_fmaf(Pw.y, Rs[1], Pw.x * Rs[0])) + ts[0];
     float p1 = __builtin_fmaf(Pw.z, Rs[5], __builtin_fmaf(Pw.y, Rs[4], Pw.x * Rs[3])) + ts[1];
     float z  = __builtin_fmaf(Pw.z, Rs[8], __builtin_fmaf(Pw.y, Rs[7], Pw.x * Rs[6])) + ts[2];
     float zz = z + 1e-8f;
-    float rz = rcp_t<LEAN>(zz, ok);
+    float rz;
+    if constexpr (LEAN && TRACK) {
+        rz = __builtin_amdgcn_rcpf(zz);
+        rz = __builtin_fmaf(rz, __builtin_fmaf(-zz, rz, 1.0f), rz);
+        const float az = __builtin_fabsf(zz);
+        *zlo = __builtin_fminf(*zlo, az);
+        *zhi = __builtin_fmaxf(*zhi, az);
+    } else {
+        rz = rcp_t<LEAN>(zz, ok);
+    }
     float a = qdiv(p0, zz, rz), b = qdiv(p1, zz, rz);
     float u = __builtin_fmaf(b, K[1], a * K[0]) + K[2];
     float v = __builtin_fmaf(b, K[4], a * K[3]) + K[5];
     // non-short-circuit '&': '&&' makes hipcc emit a branch per source here
-    valid = (z > 0.1f) & (u >= c.lo) & (u < c.hix) & (v >= c.lo) & (v < c.hiy);
+    if constexpr (NOBOUNDS) valid = (z > 0.1f) & (u < __builtin_inff()) & (v < __builtin_inff());
+    else valid = (z > 0.1f) & (u >= c.lo) & (u < c.hix) & (v >= c.lo) & (v < c.hiy);
     float gx = qdiv(2.0f * u, c.fw, c.rfw) - 1.0f;
     float gy = qdiv(2.0f * v, c.fh, c.rfh) - 1.0f;
     float ux = (gx + 1.0f) * c.hw2;

@@ -99,4 +99,162 @@ AMVS_DEV unsigned sample_sources_checked(JobCP job, const StepArgsBase &a, const
     return okbits;
 }
 
+// ------------------------------------------------------------------ window sums --
+// k x k window sums of v, v*v and r*v for S sources at once, from the per-lane vertical rings.
+//   1. column sums, top -> bottom: plain sum for v, fma chains for v*v and r*v   (registers)
+//   2. row sums, right -> left:   sum_{j=K-1..0} c(lane+j)
+// Step 2 needs the column sums of the K-1 lanes to the right.  Two implementations with the
+// same summation order (and therefore the same bits):
+//   DPP  (default): K-1 `v_add_f32_dpp ... wave_shl:1` per sum, no LDS.  A DPP add costs 3x a
+//        plain add to issue on gfx950 (tools/shift_rate.hip) but needs no extra registers.
+//   LDS  (-DAMVS_HSUM_LDS): every lane stores its 3*S column sums as NV4 float4 at a lane stride
+//        of 12 (S<=4) or 20 (S>4) dwords -- conflict-free for ds_write_b128 / ds_read_b128 -- and
+//        reads its neighbours' with (K-1)*NV4 ds_read_b128 (one wave per workgroup and in-order
+//        LDS: no barrier).  Measured within +-1.5 % of DPP (26.9 vs 26.5 G px-hyp/s before the
+//        row pipeline) at ~25 more VGPRs, so it is not the default.
+template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
+
+// Where the vertical rings live.  The ref ring and the rings of the first NL sources are kept in
+// LDS ([ring][slot][lane], rotating slot, conflict-free one-dword-per-lane accesses) instead of
+// registers: 7*(NL+1) fewer VGPRs held across the whole row loop, which is what lets the k=7, S=4
+// kernel run five waves per SIMD (the window-sum stage is its register peak today); the other
+// sources stay in shifting register rings.
+#ifndef AMVS_RING_LDS_SOURCES
+#define AMVS_RING_LDS_SOURCES 2
+#endif
+template <int S> struct Ring {
+    static constexpr int NL = AMVS_RING_LDS_SOURCES < S ? AMVS_RING_LDS_SOURCES : S;   // sources in LDS
+    static constexpr int NR = S - NL > 0 ? S - NL : 1;                                  // register rings (>=1 for the type)
+    static constexpr bool REF_IN_LDS = NL > 0;
+};
+
+template <int K, int S>
+AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], float (&ring_v)[Ring<S>::NR][K],
+                        float rv, const float (&v)[S])
+{
+    constexpr int NL = Ring<S>::NL;
+    if (Ring<S>::REF_IN_LDS) {
+        lring[wslot * AMVS_WAVE + lane] = rv;
+#pragma unroll
+        for (int s = 0; s < NL; ++s) lring[((s + 1) * K + wslot) * AMVS_WAVE + lane] = v[s];
+    } else {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring_r[i] = ring_r[i + 1];
+        ring_r[K - 1] = rv;
+    }
+#pragma unroll
+    for (int s = NL; s < S; ++s) {
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) ring_v[s - NL][i] = ring_v[s - NL][i + 1];
+        ring_v[s - NL][K - 1] = v[s];
+    }
+}
+
+// `oldest` = LDS slot of the oldest row (the next write slot once the ring is full)
+// REV: the rings were filled walking UP the image (paired-band schedule, bottom-up wave): ring entry i is
+// then row (K-1-i) of the window, and the column sums take them newest first -- the same top -> bottom
+// order of the same values.
+// REFSUMS = false (the plane sweep, whose reference statistics come from the precomputed maps): br / brr are
+// not formed.
+template <int K, int S, bool REV = false, bool REFSUMS = true>
+AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
+                          const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
+                          float (&bv)[S], float (&bvv)[S], float (&brv)[S], float &br, float &brr)
+{
+    constexpr int NV4 = HSum<S>::NV4;
+    constexpr int NL = Ring<S>::NL;
+    float cs[NV4 * 4];
+#pragma unroll
+    for (int i = 0; i < NV4 * 4; ++i) cs[i] = 0.0f;
+    // ref values of the window, oldest -> newest
+    float rr[K];
+    int slot[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const int j = REV ? K - 1 - i : i;              // window row i (top -> bottom) = ring age j
+        slot[i] = oldest + j >= K ? oldest + j - K : oldest + j;
+        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[j];
+    }
+    // window sums of the reference image itself (r, r*r): the statistics mean1 / var1 of
+    // mvs_patchmatch.py:403,406, recomputed from the ring (same order as box_stats_kernel, so the
+    // same bits) instead of streaming two precomputed maps (8 B per pixel and step)
+    if constexpr (REFSUMS) {
+        float cr = rr[0], crr = rr[0] * rr[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) { cr = cr + rr[i]; crr = __builtin_fmaf(rr[i], rr[i], crr); }
+        float ar = cr, arr = crr;
+#pragma unroll
+        for (int j = 1; j < K; ++j) { ar = wave_shl1(ar) + cr; arr = wave_shl1(arr) + crr; }
+        br = ar; brr = arr;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float vv[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            vv[i] = s < NL ? lring[((s + 1) * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][REV ? K - 1 - i : i];
+        float cv = vv[0];
+        float cvv = vv[0] * vv[0];
+        float crv = rr[0] * vv[0];
+#pragma unroll
+        for (int i = 1; i < K; ++i) {
+            cv = cv + vv[i];
+            cvv = __builtin_fmaf(vv[i], vv[i], cvv);
+            crv = __builtin_fmaf(rr[i], vv[i], crv);
+        }
+        cs[3 * s] = cv; cs[3 * s + 1] = cvv; cs[3 * s + 2] = crv;
+    }
+#ifndef AMVS_HSUM_LDS
+    (void)hbuf;
+    float acc[NV4 * 4];
+#pragma unroll
+    for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
+#pragma unroll
+    for (int j = 1; j < K; ++j)
+#pragma unroll
+        for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
+#else
+    float4 *mine = hbuf + lane * NV4;
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) mine[q] = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+    __builtin_amdgcn_wave_barrier();
+    float acc[NV4 * 4];
+    // one float4 column group at a time: its K-1 neighbour reads are issued together, then
+    // summed right -> left
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) {
+        float4 t[K - 1];
+#pragma unroll
+        for (int j = 1; j < K; ++j) t[j - 1] = mine[j * NV4 + q];
+        float4 r = t[K - 2];
+#pragma unroll
+        for (int j = K - 2; j >= 1; --j) {
+            r.x += t[j - 1].x; r.y += t[j - 1].y; r.z += t[j - 1].z; r.w += t[j - 1].w;
+        }
+        acc[4 * q] = r.x + cs[4 * q]; acc[4 * q + 1] = r.y + cs[4 * q + 1];
+        acc[4 * q + 2] = r.z + cs[4 * q + 2]; acc[4 * q + 3] = r.w + cs[4 * q + 3];
+        // pin the sums here (LLVM otherwise sinks the adds to their first use and keeps every
+        // neighbour read live across the NCC epilogue)
+        asm volatile("" : "+v"(acc[4 * q]), "+v"(acc[4 * q + 1]), "+v"(acc[4 * q + 2]), "+v"(acc[4 * q + 3]));
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
+#pragma unroll
+    for (int s = 0; s < S; ++s) { bv[s] = acc[3 * s]; bvv[s] = acc[3 * s + 1]; brv[s] = acc[3 * s + 2]; }
+}
+
+// lanes beyond the strip read (K-1) entries past lane 63: keep them defined
+template <int K, int S>
+AMVS_DEV void window_sums_init(float4 *hbuf, int lane)
+{
+#ifndef AMVS_HSUM_LDS
+    (void)hbuf; (void)lane;
+    return;
+#endif
+    constexpr int NV4 = HSum<S>::NV4;
+    if (lane < K - 1)
+#pragma unroll
+        for (int q = 0; q < NV4; ++q) hbuf[(AMVS_WAVE + lane) * NV4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace amvs

@@ -109,6 +109,10 @@ struct SweepArgs : StepArgsBase {
     float thresh;
     float *depth_out, *conf_out;             // [slot][H*W]
     const Job *jobs;
+    // exact arithmetic, compiled patch sizes: mean1 / var1 maps of every view for this patch size
+    // ([n_views][img_stride], launch_box_stats) -- plane-invariant, so the sweep loads them instead of
+    // re-forming the reference's window sums for every plane
+    const float *ref_mean, *ref_var;
 };
 
 bool patch_supported(int K);          // any odd patch size in 3 .. AMVS_MAX_PATCH

@@ -21,162 +21,6 @@
 
 namespace amvs {
 
-// ------------------------------------------------------------------ window sums --
-// k x k window sums of v, v*v and r*v for S sources at once, from the per-lane vertical rings.
-//   1. column sums, top -> bottom: plain sum for v, fma chains for v*v and r*v   (registers)
-//   2. row sums, right -> left:   sum_{j=K-1..0} c(lane+j)
-// Step 2 needs the column sums of the K-1 lanes to the right.  Two implementations with the
-// same summation order (and therefore the same bits):
-//   DPP  (default): K-1 `v_add_f32_dpp ... wave_shl:1` per sum, no LDS.  A DPP add costs 3x a
-//        plain add to issue on gfx950 (tools/shift_rate.hip) but needs no extra registers.
-//   LDS  (-DAMVS_HSUM_LDS): every lane stores its 3*S column sums as NV4 float4 at a lane stride
-//        of 12 (S<=4) or 20 (S>4) dwords -- conflict-free for ds_write_b128 / ds_read_b128 -- and
-//        reads its neighbours' with (K-1)*NV4 ds_read_b128 (one wave per workgroup and in-order
-//        LDS: no barrier).  Measured within +-1.5 % of DPP (26.9 vs 26.5 G px-hyp/s before the
-//        row pipeline) at ~25 more VGPRs, so it is not the default.
-template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
-
-// Where the vertical rings live.  The ref ring and the rings of the first NL sources are kept in
-// LDS ([ring][slot][lane], rotating slot, conflict-free one-dword-per-lane accesses) instead of
-// registers: 7*(NL+1) fewer VGPRs held across the whole row loop, which is what lets the k=7, S=4
-// kernel run five waves per SIMD (the window-sum stage is its register peak today); the other
-// sources stay in shifting register rings.
-#ifndef AMVS_RING_LDS_SOURCES
-#define AMVS_RING_LDS_SOURCES 2
-#endif
-template <int S> struct Ring {
-    static constexpr int NL = AMVS_RING_LDS_SOURCES < S ? AMVS_RING_LDS_SOURCES : S;   // sources in LDS
-    static constexpr int NR = S - NL > 0 ? S - NL : 1;                                  // register rings (>=1 for the type)
-    static constexpr bool REF_IN_LDS = NL > 0;
-};
-
-template <int K, int S>
-AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], float (&ring_v)[Ring<S>::NR][K],
-                        float rv, const float (&v)[S])
-{
-    constexpr int NL = Ring<S>::NL;
-    if (Ring<S>::REF_IN_LDS) {
-        lring[wslot * AMVS_WAVE + lane] = rv;
-#pragma unroll
-        for (int s = 0; s < NL; ++s) lring[((s + 1) * K + wslot) * AMVS_WAVE + lane] = v[s];
-    } else {
-#pragma unroll
-        for (int i = 0; i < K - 1; ++i) ring_r[i] = ring_r[i + 1];
-        ring_r[K - 1] = rv;
-    }
-#pragma unroll
-    for (int s = NL; s < S; ++s) {
-#pragma unroll
-        for (int i = 0; i < K - 1; ++i) ring_v[s - NL][i] = ring_v[s - NL][i + 1];
-        ring_v[s - NL][K - 1] = v[s];
-    }
-}
-
-// `oldest` = LDS slot of the oldest row (the next write slot once the ring is full)
-// REV: the rings were filled walking UP the image (paired-band schedule, bottom-up wave): ring entry i is
-// then row (K-1-i) of the window, and the column sums take them newest first -- the same top -> bottom
-// order of the same values.
-template <int K, int S, bool REV = false>
-AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
-                          const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
-                          float (&bv)[S], float (&bvv)[S], float (&brv)[S], float &br, float &brr)
-{
-    constexpr int NV4 = HSum<S>::NV4;
-    constexpr int NL = Ring<S>::NL;
-    float cs[NV4 * 4];
-#pragma unroll
-    for (int i = 0; i < NV4 * 4; ++i) cs[i] = 0.0f;
-    // ref values of the window, oldest -> newest
-    float rr[K];
-    int slot[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const int j = REV ? K - 1 - i : i;              // window row i (top -> bottom) = ring age j
-        slot[i] = oldest + j >= K ? oldest + j - K : oldest + j;
-        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[j];
-    }
-    // window sums of the reference image itself (r, r*r): the statistics mean1 / var1 of
-    // mvs_patchmatch.py:403,406, recomputed from the ring (same order as box_stats_kernel, so the
-    // same bits) instead of streaming two precomputed maps (8 B per pixel and step)
-    {
-        float cr = rr[0], crr = rr[0] * rr[0];
-#pragma unroll
-        for (int i = 1; i < K; ++i) { cr = cr + rr[i]; crr = __builtin_fmaf(rr[i], rr[i], crr); }
-        float ar = cr, arr = crr;
-#pragma unroll
-        for (int j = 1; j < K; ++j) { ar = wave_shl1(ar) + cr; arr = wave_shl1(arr) + crr; }
-        br = ar; brr = arr;
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        float vv[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i)
-            vv[i] = s < NL ? lring[((s + 1) * K + slot[i]) * AMVS_WAVE + lane] : ring_v[s < NL ? 0 : s - NL][REV ? K - 1 - i : i];
-        float cv = vv[0];
-        float cvv = vv[0] * vv[0];
-        float crv = rr[0] * vv[0];
-#pragma unroll
-        for (int i = 1; i < K; ++i) {
-            cv = cv + vv[i];
-            cvv = __builtin_fmaf(vv[i], vv[i], cvv);
-            crv = __builtin_fmaf(rr[i], vv[i], crv);
-        }
-        cs[3 * s] = cv; cs[3 * s + 1] = cvv; cs[3 * s + 2] = crv;
-    }
-#ifndef AMVS_HSUM_LDS
-    (void)hbuf;
-    float acc[NV4 * 4];
-#pragma unroll
-    for (int i = 0; i < 3 * S; ++i) acc[i] = cs[i];
-#pragma unroll
-    for (int j = 1; j < K; ++j)
-#pragma unroll
-        for (int i = 0; i < 3 * S; ++i) acc[i] = wave_shl1(acc[i]) + cs[i];
-#else
-    float4 *mine = hbuf + lane * NV4;
-#pragma unroll
-    for (int q = 0; q < NV4; ++q) mine[q] = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
-    __builtin_amdgcn_wave_barrier();
-    float acc[NV4 * 4];
-    // one float4 column group at a time: its K-1 neighbour reads are issued together, then
-    // summed right -> left
-#pragma unroll
-    for (int q = 0; q < NV4; ++q) {
-        float4 t[K - 1];
-#pragma unroll
-        for (int j = 1; j < K; ++j) t[j - 1] = mine[j * NV4 + q];
-        float4 r = t[K - 2];
-#pragma unroll
-        for (int j = K - 2; j >= 1; --j) {
-            r.x += t[j - 1].x; r.y += t[j - 1].y; r.z += t[j - 1].z; r.w += t[j - 1].w;
-        }
-        acc[4 * q] = r.x + cs[4 * q]; acc[4 * q + 1] = r.y + cs[4 * q + 1];
-        acc[4 * q + 2] = r.z + cs[4 * q + 2]; acc[4 * q + 3] = r.w + cs[4 * q + 3];
-        // pin the sums here (LLVM otherwise sinks the adds to their first use and keeps every
-        // neighbour read live across the NCC epilogue)
-        asm volatile("" : "+v"(acc[4 * q]), "+v"(acc[4 * q + 1]), "+v"(acc[4 * q + 2]), "+v"(acc[4 * q + 3]));
-    }
-    __builtin_amdgcn_wave_barrier();
-#endif
-#pragma unroll
-    for (int s = 0; s < S; ++s) { bv[s] = acc[3 * s]; bvv[s] = acc[3 * s + 1]; brv[s] = acc[3 * s + 2]; }
-}
-
-// lanes beyond the strip read (K-1) entries past lane 63: keep them defined
-template <int K, int S>
-AMVS_DEV void window_sums_init(float4 *hbuf, int lane)
-{
-#ifndef AMVS_HSUM_LDS
-    (void)hbuf; (void)lane;
-    return;
-#endif
-    constexpr int NV4 = HSum<S>::NV4;
-    if (lane < K - 1)
-#pragma unroll
-        for (int q = 0; q < NV4; ++q) hbuf[(AMVS_WAVE + lane) * NV4 + q] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // ------------------------------------------------------------------ sweep step ---
 // One cost evaluation + select over a batch of reference views
 // (_compute_patch_cost / _spatial_propagation / _random_refinement /
@@ -596,148 +440,6 @@ hipError_t launch_sample_dump(int S, const StepArgs &a, float *out, unsigned cha
     }
 }
 
-// ------------------------------------------------------------------ plane sweep --
-// _plane_sweep_torch (dense_stereo.py:262-310): for each of D fronto-parallel planes
-// count neighbours with NCC > thresh and z > 0.1; keep the first plane with the highest
-// count.  A wave keeps the running best of its strip and plane chunk in LDS as a 16-bit key
-// ((count << 12) | (4095 - plane index inside the chunk): a plain max implements torch.max's
-// first-index rule; 16 bits keep the strip's keys at 4 KB, which is what lets four waves per SIMD
-// fit the 160 KB of LDS) and never materialises the (D,H,W) volume the reference allocates (:262).
-// Chunks are merged through atomicMax on the 32-bit key (count << 16) | (65535 - plane).
-template <int K, int S, bool U8>
-__global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs a)
-{
-    constexpr int HALF = K / 2;
-    constexpr int OUTW = AMVS_WAVE - 2 * HALF;
-    constexpr float INV_AREA = 1.0f / (float)(K * K);
-    __shared__ uint16_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
-    __shared__ float lut[256];
-    #ifdef AMVS_HSUM_LDS
-    __shared__ float4 hbuf[(AMVS_WAVE + K - 1) * HSum<S>::NV4];
-#else
-    float4 *hbuf = nullptr;
-#endif
-    __shared__ float lring[(Ring<S>::NL + 1) * K * AMVS_WAVE];
-
-    const int lane = threadIdx.x;
-    window_sums_init<K, S>(hbuf, lane);
-    if (U8) fill_gray_lut(lut, lane);
-    const int t0 = xcd_remap(blockIdx.x, gridDim.x);
-    const int cid = t0 % a.n_chunks;          // plane chunk of this wave
-    const int t = t0 / a.n_chunks;
-    const int tiles_per_job = a.tiles_x * a.tiles_y;
-    const int job_id = t / tiles_per_job;
-    const int rem = t - job_id * tiles_per_job;
-    const int ty = rem / a.tiles_x;
-    const int tx = rem - ty * a.tiles_x;
-    const int d_begin = cid * a.chunk, d_end = min(a.D, d_begin + a.chunk);
-
-    const JobCP job = (JobCP)(a.jobs + job_id);
-    const int H = a.H, W = a.W;
-    const long long HW = (long long)H * W;
-    const float *__restrict__ ref = a.images + job->ref_img * a.img_stride;
-    const SampleConsts sc = make_sample_consts(H, W, -__builtin_inff(), __builtin_inff(), __builtin_inff());
-
-    const int xbase = tx * OUTW - HALF;
-    const int y0 = ty * a.TH;
-    const int xr = xbase + lane;
-    const bool col_in = (unsigned)xr < (unsigned)W;
-    const int trows = min(a.TH, H - y0);
-    const int rows = trows + 2 * HALF;
-
-    for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
-
-    for (int d = d_begin; d < d_end; ++d) {
-        const float depth = a.depths[d];
-        float ring_r[K];
-        float ring_v[Ring<S>::NR][K];
-        typename Hist<K, S>::T hist_ok = 0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            ring_r[i] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
-        }
-        int wslot = 0;
-
-        for (int r = 0; r < rows; ++r) {
-            const int yr = y0 - HALF + r;
-            const bool live = col_in & ((unsigned)yr < (unsigned)H);
-            const int pix = yr * W + xr;
-            const float rvl = ref[live ? pix : 0];
-            const float rv = live ? rvl : 0.0f;
-            JobCP jr = reload(job);
-            const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, depth);
-            float v[S];
-            const unsigned okbits = sample_sources_checked<S, U8, true>(jr, a, sc, lut, Pw, live, v);
-            ring_push<K, S>(lring, lane, wslot, ring_r, ring_v, rv, v);
-            wslot = wslot + 1 == K ? 0 : wslot + 1;
-            hist_ok = (hist_ok >> S) | ((typename Hist<K, S>::T)okbits << (S * HALF));
-            if (r < 2 * HALF) continue;
-
-            const int yc = yr - HALF;
-            const int xc = xr + HALF;
-            const bool outl = (lane < OUTW) & (xc < W);
-            const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
-            float bvs[S], bvvs[S], brvs[S], br, brr;
-            window_sums<K, S>(lring, wslot, ring_r, ring_v, hbuf, lane, bvs, bvvs, brvs, br, brr);
-            const float m1 = br * INV_AREA;
-            const float v1 = brr * INV_AREA - m1 * m1;
-            uint32_t votes = 0u;
-            auto vote_stage = [&](auto lean, bool &ok) {
-                constexpr bool LEAN = decltype(lean)::value;
-                votes = 0u;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float bv = bvs[s], bvv = bvvs[s], brv = brvs[s];
-                    // _compute_ncc_torch: eps inside the sqrt (dense_stereo.py:344-345)
-                    const float mean2 = bv * INV_AREA;
-                    const float var2 = bvv * INV_AREA - mean2 * mean2;
-                    const float cov = brv * INV_AREA - m1 * mean2;
-                    const float den = sqrt_t<LEAN>(v1 * var2 + 1e-8f, ok);
-                    const float ncc = qdiv(cov, den, rcp_t<LEAN>(den, ok));
-                    if (ncc > a.thresh && ((okc >> s) & 1u)) votes += 1u;   // :303-304
-                }
-            };
-            {
-                bool ok = true;
-                vote_stage(std::true_type{}, ok);
-                if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
-            }
-            if (outl) {
-                const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
-                const uint32_t cur = best[yc - y0][lane];
-                // the chunk's first plane always enters (torch.max over a volume that starts at 0
-                // votes): its key (0 << 12) | 4095 beats the initial 0
-                if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
-            }
-        }
-    }
-
-    unsigned *__restrict__ keys = a.keys + job->slot * HW;
-    const int xc = xr + HALF;
-    if (lane < OUTW && xc < W)
-        for (int i = 0; i < trows; ++i) {
-            const uint32_t b = best[i][lane];
-            const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
-        }
-}
-
-// decode the merged keys: depth of the winning plane (dense_stereo.py:310) and its vote count
-__global__ __launch_bounds__(256) void plane_sweep_finish_kernel(const unsigned *__restrict__ keys,
-                                                                 const float *__restrict__ depths, long long n,
-                                                                 float *__restrict__ depth_out,
-                                                                 float *__restrict__ conf_out)
-{
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const unsigned b = keys[i];
-        depth_out[i] = depths[65535 - (int)(b & 0xFFFFu)];
-        conf_out[i] = (float)(b >> 16);
-    }
-}
-
 // ------------------------------------------------------------------ ref stats ----
 // mean / variance of a gray image under the k x k zero-padded box filter
 // (mvs_patchmatch.py:403,406): computed once per image and patch size instead of once
@@ -989,16 +691,6 @@ static hipError_t launch_step_ks(const StepArgs &a, int nblk, hipStream_t st)
     return hipGetLastError();
 }
 
-template <int K, int S>
-static hipError_t launch_sweep_ks(const SweepArgs &a, int nblk, hipStream_t st)
-{
-    if (a.pairs)
-        hipLaunchKernelGGL((plane_sweep_kernel<K, S, true>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
-    else
-        hipLaunchKernelGGL((plane_sweep_kernel<K, S, false>), dim3(nblk), dim3(AMVS_WAVE), 0, st, a);
-    return hipGetLastError();
-}
-
 #define AMVS_FOR_S(K, FN, ...)                                      \
     switch (S) {                                                    \
     case 2: return FN<K, 2>(__VA_ARGS__);                           \
@@ -1052,30 +744,6 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
     case 11: AMVS_FOR_S(11, launch_step_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
-{
-    if (!patch_compiled(K)) return launch_sweep_generic(K, S, a, st);
-    if (a.fast) return launch_sweep_fast(K, S, a, st);
-    const int nblk = a.n_jobs * a.tiles_x * a.tiles_y * a.n_chunks;
-    switch (K) {
-    case 3: AMVS_FOR_S(3, launch_sweep_ks, a, nblk, st)
-    case 5: AMVS_FOR_S(5, launch_sweep_ks, a, nblk, st)
-    case 7: AMVS_FOR_S(7, launch_sweep_ks, a, nblk, st)
-    case 9: AMVS_FOR_S(9, launch_sweep_ks, a, nblk, st)
-    case 11: AMVS_FOR_S(11, launch_sweep_ks, a, nblk, st)
-    default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st)
-{
-    const long long n = (long long)a.n_jobs * a.H * a.W;
-    const int bx = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(plane_sweep_finish_kernel, dim3(bx), dim3(256), 0, st, a.keys, a.depths, n, a.depth_out,
-                       a.conf_out);
-    return hipGetLastError();
 }
 
 hipError_t launch_box_stats(int K, const float *images, long long img_stride, int H, int W,

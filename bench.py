@@ -53,7 +53,7 @@ def kernel_source_hash(kernel_key):
     if "_fast_" in kernel_key:
         names = ("amvs_sweep_fast.hip" if kernel_key.startswith("plane_sweep") else "amvs_kernels_fast.hip", "amvs_fast_common.h")
     else:
-        names = ("amvs_kernels.hip",)
+        names = ("amvs_sweep_exact.hip" if kernel_key.startswith("plane_sweep") else "amvs_kernels.hip", "amvs_exact_common.h")
     h = hashlib.sha1()
     for name in names + ("amvs_kernel_common.h", "amvs_device.h", "amvs_kernels.h"):
         with open(os.path.join(csrc, name), "rb") as f:

@@ -71,11 +71,11 @@ def fuzz_sweep(args, rng, amvs, make_scene, oracle):
     for case in range(args.cases):
         n = int(rng.integers(3, 8))
         H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
-        k = int(rng.choice([3, 5, 7]))
+        k = int(rng.choice([3, 5, 7, 9, 11, 13]))
         S = int(rng.integers(2, min(n - 1, 6) + 1))
         D = int(rng.integers(1, 40))
         mode = str(rng.choice(["fast", "exact"]))
-        thresh = float(rng.choice([0.8, 0.5, 0.0, -0.3]))
+        thresh = float(rng.choice([0.8, 0.5, 0.0, -0.3, 0.3, 0.97, 0.0005]))
         sc = make_scene(n, H, W, seed=int(rng.integers(1, 1000)), arc_step_deg=float(rng.choice([4.0, 10.0, 40.0])))
         grays = [(np.round(g * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0) for g in sc.grays]
         # planes from well in front of the scene to beyond it (wide arcs put some of them behind a source)

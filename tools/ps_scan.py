@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", default="32,30,24,20,16")
     ap.add_argument("--chunks", default="0,8,11,13,16,22,32")
+    ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     args = ap.parse_args()
     import torch
 
@@ -32,7 +33,7 @@ def main():
     dev = torch.device("cuda", 0)
     dmap = torch.empty((n, H, W), dtype=torch.float32, device=dev)
     conf = torch.empty((n, H, W), dtype=torch.float32, device=dev)
-    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode="fast") as eng:
+    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=args.mode) as eng:
         for i in ids:
             g = (np.round(sc.grays[i] * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0)
             eng.set_view(i, g, sc.poses[i].R, sc.poses[i].t)
