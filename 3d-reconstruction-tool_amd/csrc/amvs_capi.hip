@@ -508,7 +508,12 @@ int run_fused_schedule(amvs_ctx *c, int n_ref, int n_src, const amvs_pm_params *
     // arithmetic, one run per pair, G px-hyp/s paired / classic: k=7 1080p 43.3 / 41.9, k=5 47.3 / 46.2,
     // k=3 51.2 / 52.0 -- a one-row halo leaves nothing to save --, 2560x1440 41.6 / 39.3, 8 views of
     // 3840x2160 38.7 / 36.4, 32 views 43.0 / 41.7)
-    const bool paired = (p->schedule == AMVS_SCHEDULE_PAIRED || (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5)) &&
+    // 9x9 / 11x11 (round 4: compiled, their exchange fits four workgroups per CU, bit-identical -- and measured NOT
+    // faster: fast 11x11 36.2 paired at its best height (34 rows) against 36.4 classic, 9x9 38.2 against 39.2, exact
+    // 35.4 / 35.7 and 30.7 / 32.3: at these sizes the k - 1 cross-lane adds of the window sums, not the sampled rows,
+    // carry the launch): the automatic schedule keeps them classic
+    const bool paired = (p->schedule == AMVS_SCHEDULE_PAIRED ||
+                         (p->schedule == AMVS_SCHEDULE_AUTO && !band_major && p->patch_size >= 5 && p->patch_size <= 7)) &&
                         (fast ? amvs::step_fast_pair_supported(p->patch_size, n_src)
                               : (usable_pairs(c) != nullptr && amvs::step_pair_supported(p->patch_size, n_src)));
     int vpl = p->views_per_launch > 0 ? p->views_per_launch : default_views_per_launch(c, n_ref, p->patch_size, fast != 0);

@@ -35,7 +35,7 @@ static GenericConsts generic_consts(int K)
 }
 
 // dynamic LDS of one (single-wave) workgroup, in bytes
-static unsigned generic_step_lds(int K, int S) { return 4u * (256u + (unsigned)(S + 1) * K * AMVS_WAVE + (unsigned)(K / 2 + 1) * AMVS_WAVE + 256u); }
+static unsigned generic_step_lds(int K, int S) { return 4u * (256u + (unsigned)(S + 1) * K * AMVS_WAVE + (unsigned)(K / 2 + 1) * AMVS_WAVE + 2u * AMVS_WAVE); }
 static unsigned generic_sweep_lds(int K, int S)
 {
     return 4u * (256u + (unsigned)(S + 1) * K * AMVS_WAVE + (unsigned)(K / 2 + 1) * AMVS_WAVE) + 2u * AMVS_SWEEP_MAX_TH * AMVS_WAVE;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
     float *ring = smem + 256;                                               // [1 + S][K][64]
     uint32_t *okring = (uint32_t *)(ring + (S + 1) * K * AMVS_WAVE);        // [HALF + 1][64]
     constexpr int NQ = 2 * AMVS_WAVE;
-    uint2 *nq = (uint2 *)(okring + (HALF + 1) * AMVS_WAVE);                 // [NQ] winners waiting for their normal
+    uint32_t *nq = okring + (HALF + 1) * AMVS_WAVE;                         // [NQ] winners waiting for their normal
     int q_head = 0, q_tail = 0;
 
     const int lane = threadIdx.x;
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
             const unsigned long long won = __ballot(better);
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, pn, inb_c, depth_buffer(nb_tagged));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -278,10 +278,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
             const unsigned long long won = __ballot(better);
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc | (buf_c << 31), h0c);
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
             q_head += n;
         }
     }

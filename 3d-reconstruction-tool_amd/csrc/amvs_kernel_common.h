@@ -62,16 +62,25 @@ AMVS_DEV float depth_untag(float d, unsigned mask) { return __uint_as_float(__fl
 AMVS_DEV unsigned depth_buffer(float d) { return __float_as_uint(d) >> 31; }
 AMVS_DEV float depth_tag(float d, unsigned buffer) { return __uint_as_float(__float_as_uint(d) | (buffer << 31)); }
 
+// Queued winners: one 32-bit entry each (the queue of a wave is 2 x 64 entries = 512 bytes of LDS; round 4 --
+// 8-byte entries before -- so that the paired-band exchange of the 11 x 11 patch fits beside the rings at four
+// workgroups per CU).  Pixel indices are below 2^29 (amvs_create).
+//
 // Normal update of `n` queued refinement winners (entries head .. head+n-1 of the ring `nq`), one
 // per lane: normal <- normalize(normal + randn * range)   (mvs_patchmatch.py:475-476).  Entry: pixel
-// index with the winner's normal buffer in bit 31, hash.
-AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, float normal_range)
+// index with the winner's normal buffer in bit 31; the pixel's hash (a pure function of the pixel and the
+// launch's stream key) is formed again here.
+AMVS_DEV uint32_t refine_entry(int pc, unsigned buf_c) { return (unsigned)pc | (buf_c << 31); }
+
+AMVS_DEV void refine_normals(const uint32_t *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, float normal_range,
+                             StreamKey key)
 {
     if (lane < n) {
-        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
-        float *np = ((e.x >> 31) ? nbuf1 : nbuf0) + 3ll * (int)(e.x & 0x7FFFFFFFu);
+        const uint32_t e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
+        const uint32_t pc = e & 0x7FFFFFFFu;
+        float *np = ((e >> 31) ? nbuf1 : nbuf0) + 3ll * (int)pc;
         float g0, g1, g2;
-        rng_normals3(e.y, g0, g1, g2);
+        rng_normals3(pixel_hash(pc, key), g0, g1, g2);
         float cn0 = np[0] + g0 * normal_range;
         float cn1 = np[1] + g1 * normal_range;
         float cn2 = np[2] + g2 * normal_range;
@@ -81,26 +90,27 @@ AMVS_DEV void refine_normals(const uint2 *nq, int head, int n, int lane, float *
 }
 
 // Propagation winners (mvs_patchmatch.py:452-455), queued like the refinement winners and moved 64 at
-// a time: pixel pc takes the pre-step normal of its neighbour pn (zero outside the image, F.pad
-// :431-442) into the buffer it does not currently use.  Entry: x = pc | its current buffer << 31,
-// y = pn | neighbour inside the image << 30 | neighbour's buffer << 31 (pixel indices are below 2^29).
+// a time: pixel pc takes the pre-step normal of its neighbour pn = pc + noff (zero outside the image, F.pad
+// :431-442) into the buffer it does not currently use.  Entry: pc | neighbour inside the image << 29 |
+// neighbour's buffer << 30 | pc's current buffer << 31.
 // Nothing writes a neighbour's CURRENT normal during a propagation launch and nothing reads the
 // buffer a winner writes (StepArgs::nbuf), so the move may happen any time before the launch ends.
-AMVS_DEV uint2 propagate_entry(int pc, unsigned buf_c, int pn, bool inb_c, unsigned buf_n)
+AMVS_DEV uint32_t propagate_entry(int pc, unsigned buf_c, bool inb_c, unsigned buf_n)
 {
-    return make_uint2((unsigned)pc | (buf_c << 31), (unsigned)pn | ((inb_c ? 1u : 0u) << 30) | (buf_n << 31));
+    return (unsigned)pc | ((inb_c ? 1u : 0u) << 29) | (buf_n << 30) | (buf_c << 31);
 }
 
-AMVS_DEV void propagate_normals(const uint2 *nq, int head, int n, int lane, float *nbuf0, float *nbuf1)
+AMVS_DEV void propagate_normals(const uint32_t *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, int noff)
 {
     if (lane < n) {
-        const uint2 e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
-        const int pc = (int)(e.x & 0x7FFFFFFFu), pn = (int)(e.y & 0x3FFFFFFFu);
-        const bool inb_c = (e.y >> 30) & 1u;
+        const uint32_t e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
+        const int pc = (int)(e & 0x1FFFFFFFu);
+        const bool inb_c = (e >> 29) & 1u;
+        const int pn = inb_c ? pc + noff : 0;
         // (three consecutive dwords each way: hipcc merges them into one dwordx3 access)
-        const float *src = ((e.y >> 31) ? nbuf1 : nbuf0) + 3ll * pn;
+        const float *src = (((e >> 30) & 1u) ? nbuf1 : nbuf0) + 3ll * pn;
         const float t0 = src[0], t1 = src[1], t2 = src[2];
-        float *dst = ((e.x >> 31) ? nbuf0 : nbuf1) + 3ll * pc;
+        float *dst = ((e >> 31) ? nbuf0 : nbuf1) + 3ll * pc;
         dst[0] = inb_c ? t0 : 0.0f;
         dst[1] = inb_c ? t1 : 0.0f;
         dst[2] = inb_c ? t2 : 0.0f;
@@ -127,7 +137,7 @@ AMVS_DEV void propagate_normals(const uint2 *nq, int head, int n, int lane, floa
 #define AMVS_PAIR_COLS 2
 #endif
 constexpr int PAIR_WAVES = 2 * AMVS_PAIR_COLS;
-constexpr bool step_pair_supported_ks(int K, int S) { return K >= 5 && K <= 7 && S <= 4; }
+constexpr bool step_pair_supported_ks(int K, int S) { return K >= 5 && K <= 11 && S <= 4; }
 
 #if defined(AMVS_HSUM_LDS) && AMVS_WG_WAVES > 1
 #error "the LDS horizontal-sum variant keeps one exchange buffer per workgroup: build it with -DAMVS_WG_WAVES=1"

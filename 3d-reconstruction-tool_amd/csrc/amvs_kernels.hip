@@ -56,14 +56,17 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
 #endif
     __shared__ float lring_all[WGW * (Ring<S>::NL + 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;                    // refinement winners waiting for their normal
-    __shared__ uint2 nq_all[WGW * NQ];
-    constexpr int XW = HALF * S * AMVS_WAVE;             // floats of a wave's exchange rows [row][source][lane]
-    __shared__ float xbuf_all[PAIR ? WGW * XW : 1];
+    __shared__ uint32_t nq_all[WGW * NQ];
+    // paired bands: the partner's rows of the LDS-resident sources are read from the partner's ring itself (see
+    // pm_step_fast_kernel); exchange rows only for the XS sources with register rings
+    constexpr int XS = S - Ring<S>::NL > 0 ? S - Ring<S>::NL : 0;
+    constexpr int XW = HALF * XS * AMVS_WAVE;            // floats of a wave's exchange rows [row][register source][lane]
+    __shared__ float xbuf_all[PAIR && XS > 0 ? WGW * XW : 1];
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
     float *lring = lring_all + wv * ((Ring<S>::NL + 1) * K * AMVS_WAVE);
-    uint2 *nq = nq_all + wv * NQ;
+    uint32_t *nq = nq_all + wv * NQ;
     int q_head = 0, q_tail = 0;                          // wave-uniform; at most 63 + 58 entries queued
     window_sums_init<K, S>(hbuf, lane);
     if (U8) fill_gray_lut(lut, lane);
@@ -132,6 +135,9 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
     const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
     float *xmine = PAIR ? xbuf_all + wv * XW : nullptr;
     const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * XW : nullptr;
+    const float *lring_p = PAIR ? lring_all + (wv ^ AMVS_PAIR_COLS) * ((Ring<S>::NL + 1) * K * AMVS_WAVE) : nullptr;
+    int pslot = 0;                      // ring slot of the partner's own row next to the boundary
+    if (PAIR && paired) pslot = (min(a.TH, H - (ty ^ 1) * a.TH) + HALF - 1) % K;
 
     float ring_r[K];
     float ring_v[Ring<S>::NR][K];
@@ -198,18 +204,21 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
         if (PAIR && !own) {
             // a row of the partner band: its samples, taken at its own candidates, from LDS (the partner
             // wrote them walking towards the boundary: the row next to it last)
-            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (S * AMVS_WAVE);
+            constexpr int NLS = Ring<S>::NL;
+            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (XS * AMVS_WAVE);
 #pragma unroll
-            for (int s = 0; s < S; ++s) v[s] = xp[s * AMVS_WAVE + lane];
+            for (int s = 0; s < S; ++s)
+                v[s] = s < NLS ? lring_p[((s + 1) * K + pslot) * AMVS_WAVE + lane] : xp[(s < NLS ? 0 : s - NLS) * AMVS_WAVE + lane];
+            pslot = pslot == 0 ? K - 1 : pslot - 1;
         } else {
             JobCP jr = reload(job);
             const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, xr, yr, dc);
             okbits = sample_sources_checked<S, U8, AMVS_PM_ROW_CHECK_SAMPLING, AMVS_STEP_PRIO>(jr, a, sc, lut, Pw, live, v);
             if constexpr (PAIR) {
-                if (paired && loc >= n_own - HALF) {           // the last K/2 own rows: for the partner
-                    float *xm = xmine + (loc - (n_own - HALF)) * (S * AMVS_WAVE);
+                if (XS > 0 && paired && loc >= n_own - HALF) {  // the last K/2 own rows: for the partner
+                    float *xm = xmine + (loc - (n_own - HALF)) * (XS * AMVS_WAVE);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) xm[s * AMVS_WAVE + lane] = v[s];
+                    for (int s = Ring<S>::NL; s < S; ++s) xm[(s - Ring<S>::NL) * AMVS_WAVE + lane] = v[s];
                 }
             }
         }
@@ -338,10 +347,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, pn, inb_c, depth_buffer(nb_tagged));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -360,10 +369,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc | (buf_c << 31), h0c);
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -372,8 +381,8 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
             q_head += n;
         }
     }

@@ -23,9 +23,11 @@
 namespace amvs {
 
 template <int K, int S> struct StepLds {
-    static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 8u;
+    static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 4u;
     static constexpr unsigned STATIC = AMVS_WG_WAVES * PER_WAVE;
-    static constexpr unsigned XBUF = (K / 2) * S * AMVS_WAVE * 4u;                     // paired bands: the exchange rows of a wave
+    // paired bands: the exchange rows of a wave -- only the sources whose ring lives in registers; the others are
+    // read straight from the partner's LDS ring
+    static constexpr unsigned XBUF = (K / 2) * (S - FRing<S>::NL > 0 ? S - FRing<S>::NL : 0) * AMVS_WAVE * 4u;
     static unsigned extra(int wg_cap, bool pair = false)
     {
         // wg_cap counts workgroups of AMVS_WG_WAVES waves; a paired workgroup of PAIR_WAVES waves takes
@@ -38,9 +40,12 @@ template <int K, int S> struct StepLds {
 };
 
 // the paired-band schedule is compiled where its exchange rows fit beside the rings at 4 workgroups per CU
+// (round 4: every compiled patch size -- a band's rows of the LDS-resident sources are read from the partner's
+// ring itself, only the register-resident source goes through exchange rows: 11 x 11, S = 4: 8 448 B of rings +
+// 512 B of queue + 1 280 B of exchange rows = exactly the 10 240 B a wave may take at four workgroups per CU)
 constexpr bool fast_pair_supported(int K, int S)
 {
-    return K <= 7 && S <= 4;
+    return K <= 11 && S <= 4;
 }
 
 constexpr int fast_min_waves(int K, int S)
@@ -145,13 +150,18 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     constexpr int NL = FRing<S>::NL;
     __shared__ float lring_all[WGW * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;
-    __shared__ uint2 nq_all[WGW * NQ];
-    __shared__ float xbuf_all[PAIR ? WGW * HALF * S * AMVS_WAVE : 1];             // [wave][row][source][lane]
+    __shared__ uint32_t nq_all[WGW * NQ];
+    // Paired bands: a wave finishes its last K/2 output rows from the samples of the partner band's K/2 rows
+    // next to the boundary.  For the NL sources whose ring lives in LDS those rows ARE in the partner's ring when
+    // the partners meet (its K newest rows; the slots it overwrites afterwards hold its K/2 + 1 OLDEST rows), so
+    // they are read from there; only the XS sources with register rings go through exchange rows.
+    constexpr int XS = S - NL > 0 ? S - NL : 0;
+    __shared__ float xbuf_all[PAIR && XS > 0 ? WGW * HALF * XS * AMVS_WAVE : 1];  // [wave][row][register source][lane]
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
     float *lring = lring_all + wv * ((NL > 0 ? NL : 1) * K * AMVS_WAVE);
-    uint2 *nq = nq_all + wv * NQ;
+    uint32_t *nq = nq_all + wv * NQ;
     int q_head = 0, q_tail = 0;
     const int tiles_per_job = a.tiles_x * a.tiles_y;
     int job_id, ty, tx;
@@ -212,8 +222,12 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     const int n_loc = th_w + 2 * HALF;                         // steps this wave works
     const int n_own = paired ? th_w + HALF : n_loc;            // ... of which it samples itself
     const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
-    float *xmine = PAIR ? xbuf_all + wv * (HALF * S * AMVS_WAVE) : nullptr;
-    const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * (HALF * S * AMVS_WAVE) : nullptr;
+    float *xmine = PAIR ? xbuf_all + wv * (HALF * XS * AMVS_WAVE) : nullptr;
+    const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * (HALF * XS * AMVS_WAVE) : nullptr;
+    const float *lring_p = PAIR ? lring_all + (wv ^ AMVS_PAIR_COLS) * ((NL > 0 ? NL : 1) * K * AMVS_WAVE) : nullptr;
+    // ring slot of the partner's own row next to the boundary (its step n_own_p - 1; a step's slot is step mod K)
+    int pslot = 0;
+    if (PAIR && paired) pslot = (min(a.TH, H - (ty ^ 1) * a.TH) + HALF - 1) % K;
 
     uint32_t rb[RefBytes<K>::NB];
     float ring_v[FRing<S>::NR][K];
@@ -254,9 +268,11 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
         if (PAIR && !own) {
             // a row of the partner band: its samples, taken at its own candidates, from LDS (the partner
             // wrote them walking towards the boundary: the row next to it last)
-            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (S * AMVS_WAVE);
+            const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (XS * AMVS_WAVE);
 #pragma unroll
-            for (int s = 0; s < S; ++s) v[s] = xp[s * AMVS_WAVE + lane];
+            for (int s = 0; s < S; ++s)
+                v[s] = s < NL ? lring_p[(s * K + pslot) * AMVS_WAVE + lane] : xp[(s < NL ? 0 : s - NL) * AMVS_WAVE + lane];
+            pslot = pslot == 0 ? K - 1 : pslot - 1;
         } else if constexpr (PRE) {
             const uint32_t *__restrict__ sp = smp + (live ? pix : 0);
             uint32_t w[S];
@@ -273,10 +289,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
             const float dc = candidate_depth(a, mode, inb, d_raw, h0);
             okbits = fast_sample_sources_checked<S, true, true>(job, fc, cols, (float)yr, dc, live, v);
             if constexpr (PAIR) {
-                if (paired && loc >= n_own - HALF) {           // the last K/2 own rows: for the partner
-                    float *xm = xmine + (loc - (n_own - HALF)) * (S * AMVS_WAVE);
+                if (XS > 0 && paired && loc >= n_own - HALF) {  // the last K/2 own rows: for the partner
+                    float *xm = xmine + (loc - (n_own - HALF)) * (XS * AMVS_WAVE);
 #pragma unroll
-                    for (int s = 0; s < S; ++s) xm[s * AMVS_WAVE + lane] = v[s];
+                    for (int s = NL; s < S; ++s) xm[(s - NL) * AMVS_WAVE + lane] = v[s];
                 }
             }
         }
@@ -365,10 +381,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, pn, inb_c, depth_buffer(nb_tagged));
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -382,10 +398,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
             if (won != 0ull) {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(won >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)won, 0u));
-                if (better) nq[(q_tail + rank) & (NQ - 1)] = make_uint2((unsigned)pc | (buf_c << 31), h0c);
+                if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -394,8 +410,8 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
             q_head += n;
         }
     }

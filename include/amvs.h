@@ -87,11 +87,12 @@ typedef struct {
 #define AMVS_SCHEDULE_VIEW_MAJOR  1
 #define AMVS_SCHEDULE_BAND_MAJOR  2
 #define AMVS_SCHEDULE_SPLIT       3
-#define AMVS_SCHEDULE_PAIRED      4   /* patches up to 7x7, up to 4 sources, 8-bit images (the fast mode, and the exact mode
-                                         on its packed maps): 2 x 2 strips per workgroup, vertically adjacent bands walk
-                                         towards each other and exchange their boundary samples through LDS (K/2 halo rows
-                                         per strip instead of K - 1); elsewhere it runs as view-major.  AMVS_SCHEDULE_AUTO
-                                         chooses it for patches of 5x5 and 7x7.  The maps do not depend on the schedule.   */
+#define AMVS_SCHEDULE_PAIRED      4   /* compiled patch sizes (3 .. 11), up to 4 sources, 8-bit images (the fast mode, and the
+                                         exact mode on its packed maps): 2 x 2 strips per workgroup, vertically adjacent bands
+                                         walk towards each other and exchange their boundary samples through LDS (K/2 halo
+                                         rows per strip instead of K - 1); elsewhere it runs as view-major.
+                                         AMVS_SCHEDULE_AUTO chooses it for patches of 5x5 and 7x7 (measured faster there;
+                                         9x9 / 11x11: measured equal or slower).  The maps do not depend on the schedule.   */
 
 /* Per-call device timing of the sweep kernels (HIP events on the context
  * stream; used by bench.py for the roofline figure).                            */

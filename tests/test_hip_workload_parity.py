@@ -221,6 +221,45 @@ def test_strip_orders_give_identical_maps(mode):
 
 
 @pytest.mark.parametrize("mode", ["fast", "exact"])
+@pytest.mark.parametrize("k", [9, 11])
+def test_paired_bands_for_large_patches(mode, k):
+    """Round 4: paired bands for 9x9 and 11x11 patches -- the partner band's rows of the LDS-resident sources are
+    read from the partner's ring itself, the register-resident ones through exchange rows.  Even band counts with
+    a short last band (300 = 18 x 16 + 12), an odd count (15 bands of 20), bands shorter than the halo (4 rows:
+    the partner's "own rows next to the boundary" reach into its far halo), one band per view -- all equal to the
+    classic strips bit for bit, which the other parity tests pin to the oracle."""
+    import torch
+
+    import amvs
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    n, H, W = 5, 300, 500
+    sc = make_scene(n, H, W, seed=31, device="cuda" if torch.cuda.is_available() else "cpu")
+    grays = [(np.round(g * 255.0).clip(0, 255).astype(np.uint8)).astype(np.float32) / np.float32(255.0)
+             for g in sc.grays]
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = [pm._select_source_views(r, ids, sc.poses, k=4) for r in ids]
+    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=mode) as eng:
+        for i in ids:
+            eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+        want = eng.patchmatch(ids, sources, make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max, schedule="view-major"), 13)
+        for tr in (0, 16, 20, 4, 300):
+            got = eng.patchmatch(ids, sources, make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max, schedule="paired", tile_rows=tr), 13)
+            for a, b, what in zip(want, got, ("depth", "normal", "confidence")):
+                _eq(b, a, f"{mode} k{k} paired/{tr} {what}")
+    # and against the oracle directly (view 2)
+    from oracle import oracle
+    srcs = sources[2]
+    ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), grays[2], sc.poses[2].R, sc.poses[2].t, [grays[i] for i in srcs],
+                             [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k, mode=mode)
+    od, on, oc = ctx.patchmatch(2, 2, sc.depth_min, sc.depth_max, 13, 2)
+    _eq(want[0][2], od, f"{mode} k{k} depth vs the oracle")
+    _eq(want[1][2], on, f"{mode} k{k} normal vs the oracle")
+    _eq(want[2][2], oc, f"{mode} k{k} confidence vs the oracle")
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
 @pytest.mark.parametrize("entry", ["host", "device"])
 def test_sweep_continued_one_iteration_per_call(scene_a, mode, entry):
     """amvs_pm_params.first_iteration: a sweep run as one call per iteration (the confidence pass only in
