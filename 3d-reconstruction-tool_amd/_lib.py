@@ -120,6 +120,7 @@ SIGNATURES = {
     "amvs_write_ply": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64]),
     "amvs_knn_mean_distance": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double)]),
     "amvs_selftest_lean_math": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "amvs_index_check": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "amvs_rng_fill": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, f32p, f32p]),
 }
 
@@ -164,3 +165,15 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def index_check(reset=True):
+    """(violations, translation unit, source line, index, extent) of the index-checked build (include/amvs.h
+    amvs_index_check); zeros from the shipped build."""
+    r = (C.c_uint64 * 4)()
+    load().amvs_index_check(r, int(bool(reset)))
+    return int(r[0]), int(r[1]) >> 32, int(r[1]) & 0xFFFFFFFF, int(r[2]), int(r[3])
+
+
+def index_checks_enabled():
+    return b"+index-checks" in load().amvs_version()

@@ -21,9 +21,46 @@
 
 static_assert(AMVS_MAX_SRC == AMVS_KMAX_SRC, "source-count limits out of sync");
 
+#ifdef AMVS_CHECK_INDICES
+// index-checked build (amvs_check.h): one device-side report per kernel translation unit
+namespace amvs {
+void check_fetch_kernels(unsigned long long out[4], bool reset);
+void check_fetch_kernels_fast(unsigned long long out[4], bool reset);
+void check_fetch_sweep_fast(unsigned long long out[4], bool reset);
+void check_fetch_sweep_exact(unsigned long long out[4], bool reset);
+void check_fetch_generic(unsigned long long out[4], bool reset);
+void check_fetch_extended(unsigned long long out[4], bool reset);
+void check_fetch_fusion(unsigned long long out[4], bool reset);
+void check_fetch_knn(unsigned long long out[4], bool reset);
+}  // namespace amvs
+#endif
+
 namespace {
 
 std::string g_create_error;
+
+// Sum of the violations all kernels have counted since the last reset and the record of the first one found
+// (out[1] = translation unit << 32 | source line: 1 amvs_kernels, 2 amvs_kernels_fast, 3 amvs_sweep_fast,
+// 4 amvs_sweep_exact, 5 amvs_generic, 6 amvs_extended, 7 amvs_fusion, 8 amvs_knn; out[2] = the index, out[3] = the
+// extent it was compared with).  Zeros in the shipped build.
+void index_report(uint64_t out[4], bool reset)
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+#ifdef AMVS_CHECK_INDICES
+    (void)hipDeviceSynchronize();
+    void (*const fetch[])(unsigned long long[4], bool) = {
+        amvs::check_fetch_kernels, amvs::check_fetch_kernels_fast, amvs::check_fetch_sweep_fast, amvs::check_fetch_sweep_exact,
+        amvs::check_fetch_generic, amvs::check_fetch_extended, amvs::check_fetch_fusion, amvs::check_fetch_knn};
+    for (auto f : fetch) {
+        unsigned long long r[4] = {0, 0, 0, 0};
+        f(r, reset);
+        if (r[0] && !out[0]) { out[1] = r[1]; out[2] = r[2]; out[3] = r[3]; }
+        out[0] += r[0];
+    }
+#else
+    (void)reset;
+#endif
+}
 
 struct Stats {
     float *mean = nullptr, *var = nullptr;
@@ -124,6 +161,25 @@ int fail(amvs_ctx *c, int code, const std::string &msg)
             return fail((c), AMVS_EHIP,                                                   \
                         std::string(#call) + ": " + hipGetErrorString(e_));               \
     } while (0)
+
+// end of a synchronising entry point: in the index-checked build a recorded violation turns success into
+// AMVS_EINDEX (the report stays until amvs_index_check resets it)
+int checked(amvs_ctx *c, int rc)
+{
+#ifdef AMVS_CHECK_INDICES
+    if (rc == AMVS_OK) {
+        uint64_t r[4];
+        index_report(r, false);
+        if (r[0])
+            return fail(c, AMVS_EINDEX, "index check: " + std::to_string(r[0]) + " out-of-range accesses; first in translation unit " +
+                                            std::to_string(r[1] >> 32) + " line " + std::to_string(r[1] & 0xFFFFFFFFull) + ": index " +
+                                            std::to_string((long long)r[2]) + ", extent " + std::to_string((long long)r[3]));
+    }
+#else
+    (void)c;
+#endif
+    return rc;
+}
 
 int bind_device(amvs_ctx *c)
 {
@@ -756,7 +812,18 @@ int download_state(amvs_ctx *c, size_t hw, int dbuf, float *depth, float *normal
 #pragma GCC visibility push(default)
 extern "C" {
 
+#ifdef AMVS_CHECK_INDICES
+const char *amvs_version(void) { return "amvs 0.1 (gfx950) +index-checks"; }
+#else
 const char *amvs_version(void) { return "amvs 0.1 (gfx950)"; }
+#endif
+
+int amvs_index_check(uint64_t report[4], int reset)
+{
+    if (!report) return AMVS_EINVAL;
+    index_report(report, reset != 0);
+    return AMVS_OK;
+}
 
 const char *amvs_last_error(const amvs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -871,7 +938,7 @@ int amvs_sync(amvs_ctx *c)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
-    return AMVS_OK;
+    return checked(c, AMVS_OK);
 }
 
 static int set_view_common(amvs_ctx *c, int view, const void *gray, const float R[9], const float t[3],
@@ -1097,7 +1164,7 @@ int amvs_patchmatch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *src_i
         HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw * n_ref, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
-    return AMVS_OK;
+    return checked(c, AMVS_OK);
 }
 
 int amvs_get_timing(const amvs_ctx *c, amvs_timing *out)
@@ -1298,7 +1365,7 @@ int amvs_plane_sweep(amvs_ctx *c, int ref, const int *nbr_ids, int n_nbr, const 
     HIPCHK(c, hipMemcpyAsync(conf_out, c->d_aux, 4 * hw, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     resolve_timing(c);
-    return AMVS_OK;
+    return checked(c, AMVS_OK);
 }
 
 int amvs_plane_sweep_batch(amvs_ctx *c, int n_ref, const int *ref_ids, const int *nbr_ids, int n_nbr,
@@ -1810,7 +1877,7 @@ int amvs_fetch_cloud(amvs_ctx *c, double *points, uint8_t *colors)
     HIPCHK(c, hipMemcpyAsync(points, c->d_cloud_pts, sizeof(double) * 3 * c->cloud_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(colors, c->d_cloud_rgb, 3 * c->cloud_n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return AMVS_OK;
+    return checked(c, AMVS_OK);
 }
 
 // utils.save_ply (utils.py:8-37): ASCII PLY, "%.6f %.6f %.6f %d %d %d" per vertex.  Host-only:

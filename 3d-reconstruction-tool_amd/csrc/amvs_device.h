@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "amvs_check.h"
+
 #define AMVS_WAVE 64
 #define AMVS_DEV __device__ __forceinline__
 
@@ -391,7 +393,7 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
         // (24-bit multiply: rows and pitch are far below 2^24; the full 32-bit one is a 64-bit mad)
         const unsigned idx = __umul24((unsigned)(cy + AMVS_PAIR_BORDER), (unsigned)(W + 2 * AMVS_PAIR_BORDER)) +
                              (unsigned)(cx + AMVS_PAIR_BORDER);
-        g.off = live ? (int)idx : 0;
+        g.off = AMVS_IDX(live ? (int)idx : 0, (H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - 1);   // (a footprint is 2 ushorts)
     } else {
         const int x0i = (int)x0, y0i = (int)y0;       // saturating conversion; NaN -> 0
         const bool x0ok = (x0 >= 0.0f) & (x0 <= c.fw), x1ok = (x1 >= 0.0f) & (x1 <= c.fw);
@@ -400,8 +402,8 @@ AMVS_DEV TapGeom<U8> sample_geom(KP K, RP Rs, TP ts, const SampleConsts &c, Vec3
                 ((x0ok & y1ok) ? 1u << 26 : 0u) | ((x1ok & y1ok) ? 1u << 27 : 0u);
         const int ix0 = min(max(x0i, 0), W - 1), ix1 = min(max((int)x1, 0), W - 1);
         const int iy0 = min(max(y0i, 0), H - 1), iy1 = min(max((int)y1, 0), H - 1);
-        g.o00 = live ? iy0 * W + ix0 : 0; g.o01 = live ? iy0 * W + ix1 : 0;
-        g.o10 = live ? iy1 * W + ix0 : 0; g.o11 = live ? iy1 * W + ix1 : 0;
+        g.o00 = AMVS_IDX(live ? iy0 * W + ix0 : 0, H * W); g.o01 = AMVS_IDX(live ? iy0 * W + ix1 : 0, H * W);
+        g.o10 = AMVS_IDX(live ? iy1 * W + ix0 : 0, H * W); g.o11 = AMVS_IDX(live ? iy1 * W + ix1 : 0, H * W);
     }
     return g;
 }

@@ -22,6 +22,7 @@
 //               random hypothesis.
 //   consistency number of sources whose own depth map agrees after forward-backward reprojection
 //               (pixel error < 1, relative depth error < 1 %); fusion keeps pixels with enough of them.
+#define AMVS_TU_ID 6
 #include "amvs_kernel_common.h"
 
 namespace amvs {
@@ -36,7 +37,7 @@ AMVS_DEV float xbilinear(const float *img, int H, int W, float u, float v, bool 
     if (!inside) return 0.0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
     const float fx = u - x0f, fy = v - y0f;
-    const float *p = img + (long long)y0 * W + x0;
+    const float *p = img + AMVS_IDX((long long)y0 * W + x0, (long long)H * W - W - 1);   // (reads p[0], p[1], p[W], p[W + 1])
     const float top = __builtin_fmaf(fx, p[1] - p[0], p[0]);
     const float bot = __builtin_fmaf(fx, p[W + 1] - p[W], p[W]);
     return __builtin_fmaf(fy, bot - top, top);
@@ -105,7 +106,7 @@ AMVS_DEV float xcost(const XArgs &a, JobCP job, const float *ref, int x, int y, 
                 bool inside;
                 const float sval = xbilinear(img, H, W, u, v, inside);
                 if (!inside) { ok = false; break; }
-                const float rval = ref[(long long)qy * W + qx];
+                const float rval = ref[AMVS_IDX((long long)qy * W + qx, (long long)H * W)];
                 sr += rval; sv += sval; srr = __builtin_fmaf(rval, rval, srr); svv = __builtin_fmaf(sval, sval, svv);
                 srv = __builtin_fmaf(rval, sval, srv);
                 ++cnt;
@@ -145,7 +146,7 @@ AMVS_DEV XRef<N> xref_load(const XArgs &a, const float *ref, int x, int y)
     for (int j = 0; j < N; ++j)
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const float v = R.inside ? ref[(long long)(y - half + j * st) * a.W + (x - half + i * st)] : 0.0f;
+            const float v = R.inside ? ref[AMVS_IDX((long long)(y - half + j * st) * a.W + (x - half + i * st), (long long)a.H * a.W)] : 0.0f;
             R.r[j * N + i] = v;
             R.sr += v;
             R.srr = __builtin_fmaf(v, v, R.srr);
@@ -232,14 +233,14 @@ AMVS_DEV float xcost_t(const XArgs &a, JobCP job, const XRef<N> &R, int x, int y
                 const float fx = u - x0f, fy = v - y0f;
                 float top, bot;
                 if constexpr (U8) {
-                    const uint32_t wd = load_pair_word(pimg, (yi + PB) * ppitch + xi + PB, 0);
+                    const uint32_t wd = load_pair_word(pimg, AMVS_IDX((yi + PB) * ppitch + xi + PB, (a.H + 2 * PB) * ppitch - 1), 0);
                     // bytes: (y,x) (y+1,x) (y,x+1) (y+1,x+1)
                     const float t00 = (float)(wd & 0xFFu), t10 = (float)((wd >> 8) & 0xFFu);
                     const float t01 = (float)((wd >> 16) & 0xFFu), t11 = (float)(wd >> 24);
                     top = __builtin_fmaf(fx, t01 - t00, t00);
                     bot = __builtin_fmaf(fx, t11 - t10, t10);
                 } else {
-                    const float *pp = img + (long long)yi * a.W + xi;
+                    const float *pp = img + AMVS_IDX((long long)yi * a.W + xi, (long long)a.H * a.W - a.W - 1);
                     top = __builtin_fmaf(fx, pp[1] - pp[0], pp[0]);
                     bot = __builtin_fmaf(fx, pp[a.W + 1] - pp[a.W], pp[a.W]);
                 }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void xpm_view_candidates_kernel(const XArgs a)
             const int px = (int)__builtin_rintf(__builtin_fmaf(d, q0, b[0]) / p2);
             const int py = (int)__builtin_rintf(__builtin_fmaf(d, q1, b[1]) / p2);
             if ((unsigned)px < (unsigned)W && (unsigned)py < (unsigned)H) {
-                const long long j = (long long)py * W + px;
+                const long long j = AMVS_IDX((long long)py * W + px, HW);
                 const float d2 = sd[j];
                 const float n0 = sn[3 * j], n1 = sn[3 * j + 1], n2 = sn[3 * j + 2];
                 // plane in the source frame: n'.Y = n'.(d' K^-1 p'), to the world, to the reference frame
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256) void xpm_view_candidates_kernel(const XArgs a)
                 }
             }
         }
+        (void)AMVS_IDX(job->slot, a.n_jobs);                    // (the candidates are indexed by the job's slot)
         a.cand_d[cbase + i] = cd;
         a.cand_n[3 * (cbase + i)] = cnx; a.cand_n[3 * (cbase + i) + 1] = cny; a.cand_n[3 * (cbase + i) + 2] = cnz;
     }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(128) void xpm_sweep_kernel(const XArgs a)
         const int y = (int)(h / hw);
         const int x = 2 * (int)(h - (long long)y * hw) + ((y + a.colour) & 1);
         if (x >= W) continue;
-        const long long i = (long long)y * W + x;
+        const long long i = AMVS_IDX((long long)y * W + x, HW);
         float bd = D[i], bnx = N[3 * i], bny = N[3 * i + 1], bnz = N[3 * i + 2];
         float bc = C[i];
         const float rpx = __builtin_fmaf(Ki[1], (float)y, __builtin_fmaf(Ki[0], (float)x, Ki[2]));
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(128) void xpm_sweep_kernel(const XArgs a)
                 const int xx = x + (k == 0 ? -1 : (k == 1 ? 1 : 0)), yy = y + (k == 2 ? -1 : (k == 3 ? 1 : 0));
                 have = ((unsigned)xx < (unsigned)W) & ((unsigned)yy < (unsigned)H);
                 if (have) {
-                    const long long j = (long long)yy * W + xx;
+                    const long long j = AMVS_IDX((long long)yy * W + xx, HW);
                     const float nd = D[j];
                     nx = N[3 * j]; ny = N[3 * j + 1]; nz = N[3 * j + 2];
                     const float rqx = __builtin_fmaf(Ki[1], (float)yy, __builtin_fmaf(Ki[0], (float)xx, Ki[2]));
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void xpm_consistency_kernel(const XArgs a, flo
                 const int px = (int)__builtin_rintf(__builtin_fmaf(d, q0, b[0]) / p2);
                 const int py = (int)__builtin_rintf(__builtin_fmaf(d, q1, b[1]) / p2);
                 if ((unsigned)px >= (unsigned)W || (unsigned)py >= (unsigned)H) continue;
-                const float d2 = a.depth[(long long)sv * HW + (long long)py * W + px];
+                const float d2 = a.depth[(long long)sv * HW + AMVS_IDX((long long)py * W + px, HW)];
                 // the source's point -> world -> reference camera -> pixel
                 float Y[3] = {__builtin_fmaf(Ki[1], (float)py, __builtin_fmaf(Ki[0], (float)px, Ki[2])) * d2,
                               __builtin_fmaf(Ki[4], (float)py, __builtin_fmaf(Ki[3], (float)px, Ki[5])) * d2, d2};
@@ -567,3 +569,5 @@ hipError_t launch_xpm_consistency(const XArgs &a, float *conf_out, float max_px,
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(extended)

@@ -60,6 +60,7 @@ struct FastConsts {
     float cl_lo, cl_hix, cl_hiy;  // clamp of the footprint origin in (u - lo, v - lo) coordinates
     int pitch2;                   // bytes per row of the padded map
     int addc2;                    // byte offset of footprint origin (-(B+lo), -(B+lo)) ... see fast_geom
+    int max_off;                  // byte offsets of a footprint's dword lie in [0, max_off) (index-checked build only)
 };
 
 AMVS_DEV FastConsts make_fast_consts(int H, int W, int lo)
@@ -74,6 +75,7 @@ AMVS_DEV FastConsts make_fast_consts(int H, int W, int lo)
     c.cl_hiy = uniform_f((float)(H - lo));
     c.pitch2 = 2 * (W + 2 * B);
     c.addc2 = 2 * (lo + B) * (W + 2 * B + 1);
+    c.max_off = 2 * (H + 2 * B) * (W + 2 * B) - 3;
     return c;
 }
 
@@ -140,7 +142,7 @@ AMVS_DEV FastTap fast_geom(MP M, BP b, const FastConsts &fc, const FastCol &col,
     const int xi = (int)__builtin_amdgcn_fmed3f(x0, fc.cl_lo, fc.cl_hix);
     const int yi = (int)__builtin_amdgcn_fmed3f(y0, fc.cl_lo, fc.cl_hiy);
     // byte offset from the first element of the padded map: ((yi+lo+B) * pitch + xi+lo+B) * 2 >= 0
-    t.off = __mul24(yi, fc.pitch2) + fc.addc2 + (xi << 1);
+    t.off = AMVS_IDX(__mul24(yi, fc.pitch2) + fc.addc2 + (xi << 1), fc.max_off);
     return t;
 }
 

@@ -5,6 +5,8 @@
 // compaction (np.where order), np.median / np.percentile(95, linear) on device-sorted columns,
 // voxel de-duplication as a stable radix sort of the int64 keys keeping the first point of every
 // run (np.unique(return_index=True)).  hipCUB supplies the scans / sorts / selects.
+#define AMVS_TU_ID 7
+#include "amvs_check.h"
 #include "amvs_kernels.h"
 
 #include <hipcub/hipcub.hpp>
@@ -63,12 +65,12 @@ __global__ __launch_bounds__(256) void fuse_project_kernel(const long long *__re
                                                            const unsigned char *__restrict__ bgr, int H, int W,
                                                            const double *__restrict__ Kinv,
                                                            const double *__restrict__ poses,   // [n_maps][12]: R row-major, t
-                                                           double *__restrict__ pts, unsigned char *__restrict__ rgb)
+                                                           int n_maps, double *__restrict__ pts, unsigned char *__restrict__ rgb)
 {
     const long long HW = (long long)H * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long g = sel[i];
+        const long long g = AMVS_IDX(sel[i], (long long)n_maps * HW);        // (pixel of the stacked maps)
         const int map = (int)(g / HW);
         const long long p = g - map * HW;
         const double y = (double)(p / W), x = (double)(p % W);
@@ -115,11 +117,11 @@ __global__ __launch_bounds__(256) void below_kernel(const double *__restrict__ d
 
 // voxel key of mvs_patchmatch.py:583-586 for the points selected by `sel`
 __global__ __launch_bounds__(256) void voxel_key_kernel(const double *__restrict__ pts, const long long *__restrict__ sel,
-                                                        long long m, double voxel, long long *__restrict__ keys)
+                                                        long long m, long long m_src, double voxel, long long *__restrict__ keys)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long s = sel[i];
+        const long long s = AMVS_IDX(sel[i], m_src);                          // (point of the source cloud)
         const long long ix = (long long)floor(pts[3 * s] / voxel);
         const long long iy = (long long)floor(pts[3 * s + 1] / voxel);
         const long long iz = (long long)floor(pts[3 * s + 2] / voxel);
@@ -145,12 +147,12 @@ __global__ __launch_bounds__(256) void iota_kernel(long long *__restrict__ out, 
 // out[i] = src[map[idx[i]]] for points and colours
 __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ pts, const unsigned char *__restrict__ rgb,
                                                      const long long *__restrict__ sel, const long long *__restrict__ pick,
-                                                     long long m, double *__restrict__ pts_out,
+                                                     long long m, long long m_sel, long long m_src, double *__restrict__ pts_out,
                                                      unsigned char *__restrict__ rgb_out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
          i += (long long)gridDim.x * blockDim.x) {
-        const long long s = sel[pick[i]];
+        const long long s = AMVS_IDX(sel[AMVS_IDX(pick[i], m_sel)], m_src);
 #pragma unroll
         for (int j = 0; j < 3; ++j) { pts_out[3 * i + j] = pts[3 * s + j]; rgb_out[3 * i + j] = rgb[3 * s + j]; }
     }
@@ -196,7 +198,7 @@ hipError_t sort_keys(double *in, double *out, long long n, Scratch &tmp, hipStre
 
 // First point of every voxel in key order (np.unique(keys, return_index=True)) among the points
 // sel[0 .. m2) of (pts, rgb): stable radix sort of the int64 keys, heads of the runs, gather.
-hipError_t voxel_first_of_key(const double *pts, const unsigned char *rgb, const long long *sel, long long m2,
+hipError_t voxel_first_of_key(const double *pts, const unsigned char *rgb, long long m_src, const long long *sel, long long m2,
                               double voxel, Scratch &tmp, Scratch &flag, Scratch &cnt, double **pts2_out,
                               unsigned char **rgb2_out, long long *m3_out, hipStream_t st)
 {
@@ -205,7 +207,7 @@ hipError_t voxel_first_of_key(const double *pts, const unsigned char *rgb, const
     FCHK(keysA.need(8 * m2)); FCHK(keysB.need(8 * m2)); FCHK(idxA.need(8 * m2)); FCHK(idxB.need(8 * m2));
     FCHK(pick.need(8 * m2));
     FCHK(flag.need(m2));
-    hipLaunchKernelGGL(voxel_key_kernel, grid_for(m2), dim3(256), 0, st, pts, sel, m2, voxel, (long long *)keysA.p);
+    hipLaunchKernelGGL(voxel_key_kernel, grid_for(m2), dim3(256), 0, st, pts, sel, m2, m_src, voxel, (long long *)keysA.p);
     hipLaunchKernelGGL(iota_kernel, grid_for(m2), dim3(256), 0, st, (long long *)idxA.p, m2);
     {
         size_t bytes = 0;
@@ -232,7 +234,7 @@ hipError_t voxel_first_of_key(const double *pts, const unsigned char *rgb, const
     FCHK(hipMalloc(&pts2, sizeof(double) * 3 * (m3 > 0 ? m3 : 1)));
     hipError_t e = hipMalloc(&rgb2, 3 * (m3 > 0 ? m3 : 1));
     if (e != hipSuccess) { (void)hipFree(pts2); return e; }
-    hipLaunchKernelGGL(gather_kernel, grid_for(m3), dim3(256), 0, st, pts, rgb, sel, (const long long *)pick.p, m3, pts2, rgb2);
+    hipLaunchKernelGGL(gather_kernel, grid_for(m3), dim3(256), 0, st, pts, rgb, sel, (const long long *)pick.p, m3, m2, m_src, pts2, rgb2);
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(pts2); (void)hipFree(rgb2); return e; }
     *pts2_out = pts2; *rgb2_out = rgb2; *m3_out = m3;
@@ -276,7 +278,7 @@ hipError_t fuse_filter(const float *depth, const float *conf, const unsigned cha
     hipError_t e = hipMalloc(&rgb, 3 * m);
     if (e != hipSuccess) { (void)hipFree(pts); return e; }
     hipLaunchKernelGGL(fuse_project_kernel, grid_for(m), dim3(256), 0, st, (const long long *)sel.p, m, depth, bgr, H,
-                       W, d_Kinv, d_poses, pts, rgb);
+                       W, d_Kinv, d_poses, n_maps, pts, rgb);
     auto bail = [&](hipError_t err) { (void)hipFree(pts); (void)hipFree(rgb); return err; };
     if (!do_filter) {
         e = hipStreamSynchronize(st);
@@ -327,7 +329,7 @@ hipError_t fuse_filter(const float *depth, const float *conf, const unsigned cha
     double *pts2 = nullptr;
     unsigned char *rgb2 = nullptr;
     long long m3 = 0;
-    e = voxel_first_of_key(pts, rgb, (const long long *)sel.p, m2, 0.01, tmp, flag, cnt, &pts2, &rgb2, &m3, st);
+    e = voxel_first_of_key(pts, rgb, m, (const long long *)sel.p, m2, 0.01, tmp, flag, cnt, &pts2, &rgb2, &m3, st);
     (void)hipFree(pts); (void)hipFree(rgb);
     if (e != hipSuccess) return e;
     *pts_out = pts2; *rgb_out = rgb2;
@@ -375,7 +377,7 @@ hipError_t stereo_backproject(const float *depth, const float *conf, const unsig
     hipError_t e = hipMalloc(&rgb, 3 * m);
     if (e != hipSuccess) { (void)hipFree(pts); return e; }
     hipLaunchKernelGGL(fuse_project_kernel, grid_for(m), dim3(256), 0, st, (const long long *)sel.p, m, depth, bgr, H,
-                       W, d_Kinv, d_poses, pts, rgb);
+                       W, d_Kinv, d_poses, n_maps, pts, rgb);
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(pts); (void)hipFree(rgb); return e; }
     *pts_out = pts; *rgb_out = rgb;
@@ -404,7 +406,9 @@ hipError_t voxel_downsample(const double *pts, const unsigned char *rgb, long lo
         hipLaunchKernelGGL(iota_kernel, grid_for(m), dim3(256), 0, st, (long long *)sel.p, m);
     }
     if (m2 == 0) return hipSuccess;
-    return voxel_first_of_key(pts, rgb, (const long long *)sel.p, m2, voxel, tmp, flag, cnt, pts_out, rgb_out, m_out, st);
+    return voxel_first_of_key(pts, rgb, m, (const long long *)sel.p, m2, voxel, tmp, flag, cnt, pts_out, rgb_out, m_out, st);
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(fusion)

@@ -13,6 +13,7 @@
 //   * both arithmetic modes (FAST: precomposed projections, 8-bit code sums, precomputed reference statistics);
 //   * the classic schedule only (no paired bands, no split schedule), modes selected at run time.
 // It is a fallback: correct for every k, tuned for none.
+#define AMVS_TU_ID 5
 #include "amvs_exact_common.h"
 #include "amvs_fast_common.h"
 
@@ -143,14 +144,14 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const float d_raw = d_in[inb ? pix + noff : 0];
+        const float d_raw = d_in[AMVS_IDX(inb ? pix + noff : 0, HW)];
         // (clamped index, no branch in the load path: dead lanes read element 0)
         float rv;
         if constexpr (U8) {
-            const uint32_t code = ref_pairs[live ? pix + PADW * yr : 0] & 0xFFu;
+            const uint32_t code = ref_pairs[AMVS_IDX_LOHI(live ? pix + PADW * yr : 0, -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))] & 0xFFu;
             rv = FAST ? (float)code : lut[code];
         } else {
-            rv = ref[live ? pix : 0];
+            rv = ref[AMVS_IDX(live ? pix : 0, HW)];
         }
         rv = live ? rv : 0.0f;
 
@@ -188,13 +189,13 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
         const int yc = yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
-        const int pc = outl ? yc * W + xc : 0;
+        const int pc = AMVS_IDX(outl ? yc * W + xc : 0, HW);
         const float oldd_tagged = d_in[pc], oldc = cost_io[pc];
         const float oldd = depth_untag(oldd_tagged, a.depth_mask);
         const unsigned buf_c = depth_buffer(oldd_tagged);
         // lanes without an output pixel have pc = 0: they must not form pc + noff (it can lie before the map)
         const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-        const int pn = (outl & inb_c) ? pc + noff : 0;
+        const int pn = AMVS_IDX((outl & inb_c) ? pc + noff : 0, HW);
         const float nb_tagged = mode == MODE_PROP ? d_in[pn] : 0.0f;
         // the centre pixel was sampled by lane + HALF, HALF rows ago; its hash is a pure function of the pixel
         const unsigned okc = okring[okslot * AMVS_WAVE + ((lane + HALF) & (AMVS_WAVE - 1))];
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -290,8 +291,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void pm_step_generic_kernel(const StepAr
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff, (int)HW);
             q_head += n;
         }
     }
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_generic_kernel(const Sw
     for (int i = 0; i < trows; ++i) best[i * AMVS_WAVE + lane] = (uint16_t)0;
 
     for (int d = d_begin; d < d_end; ++d) {
-        const float depth = a.depths[d];
+        const float depth = a.depths[AMVS_IDX(d, a.D)];
         int wslot = 0, okslot = 0;
         // (the rings need no clearing between planes: a window is read only after its 2 HALF + 1 rows were written)
         for (int r = 0; r < rows; ++r) {
@@ -354,10 +355,10 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_generic_kernel(const Sw
             // (clamped index, no branch in the load path: dead lanes read element 0)
             float rv;
             if constexpr (U8) {
-                const uint32_t code = ref_pairs[live ? pix + PADW * yr : 0] & 0xFFu;
+                const uint32_t code = ref_pairs[AMVS_IDX_LOHI(live ? pix + PADW * yr : 0, -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))] & 0xFFu;
                 rv = FAST ? (float)code : lut[code];
             } else {
-                rv = ref[live ? pix : 0];
+                rv = ref[AMVS_IDX(live ? pix : 0, HW)];
             }
             rv = live ? rv : 0.0f;
             float v[S];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_generic_kernel(const Sw
             generic_window_sums<S, !FAST>(ring, K, wslot, lane, acc);
             uint32_t votes = 0u;
             if constexpr (FAST) {
-                const f32x2_t mv1 = ref_stats[outl ? yc * W + xc : 0];
+                const f32x2_t mv1 = ref_stats[AMVS_IDX(outl ? yc * W + xc : 0, HW)];
                 const float m1 = mv1.x, v1 = mv1.y;
                 if (a.thresh > 0.0f) {
                     // ncc > thresh (dense_stereo.py:303) as cov > 0, x >= 0, cov^2 > t^2 x (plane_sweep_fast_kernel)
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_generic_kernel(const Sw
         for (int i = 0; i < trows; ++i) {
             const uint32_t b = best[i * AMVS_WAVE + lane];
             const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
+            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], ((b >> 12) << 16) | (65535u - plane));
         }
 }
 
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_generic_kernel(const floa
         float cr = 0.0f, crr = 0.0f;
         for (int k = 0; k < K; ++k) {
             const int yy = yc - HALF + k;
-            const float rv = (col_in & ((unsigned)yy < (unsigned)H)) ? img[yy * W + xr] : 0.0f;
+            const float rv = (col_in & ((unsigned)yy < (unsigned)H)) ? img[AMVS_IDX(yy * W + xr, (long long)H * W)] : 0.0f;
             if (k == 0) { cr = rv; crr = rv * rv; }
             else { cr = cr + rv; crr = __builtin_fmaf(rv, rv, crr); }
         }
@@ -479,8 +480,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_generic_kernel(const floa
         const int xc = xr + HALF;
         if (lane < OUTW && xc < W) {
             const float m = br * gc.inv_area;
-            mo[yc * W + xc] = m;
-            vo[yc * W + xc] = brr * gc.inv_area - m * m;
+            mo[AMVS_IDX(yc * W + xc, (long long)H * W)] = m;
+            vo[AMVS_IDX(yc * W + xc, (long long)H * W)] = brr * gc.inv_area - m * m;
         }
     }
 }
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void fast_stats_generic_kernel(const uint16_t 
             for (int dx = -HALF; dx <= HALF; ++dx) {
                 const int xx = x + dx;
                 if ((unsigned)xx >= (unsigned)W) continue;
-                const int c = pairs[(long long)(yy + B) * PW + xx + B] & 0xFF;
+                const int c = pairs[AMVS_IDX((long long)(yy + B) * PW + xx + B, (long long)(H + 2 * B) * PW)] & 0xFF;
                 sr += c; srr += c * c;
             }
         }
@@ -606,3 +607,5 @@ hipError_t launch_fast_stats_generic(int K, const uint16_t *pairs_view, int H, i
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(generic)

@@ -73,12 +73,13 @@ AMVS_DEV float depth_tag(float d, unsigned buffer) { return __uint_as_float(__fl
 AMVS_DEV uint32_t refine_entry(int pc, unsigned buf_c) { return (unsigned)pc | (buf_c << 31); }
 
 AMVS_DEV void refine_normals(const uint32_t *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, float normal_range,
-                             StreamKey key)
+                             StreamKey key, int hw)
 {
+    (void)hw;                                                  // (pixels per map: the index-checked build's extent)
     if (lane < n) {
         const uint32_t e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
         const uint32_t pc = e & 0x7FFFFFFFu;
-        float *np = ((e >> 31) ? nbuf1 : nbuf0) + 3ll * (int)pc;
+        float *np = ((e >> 31) ? nbuf1 : nbuf0) + 3ll * AMVS_IDX((int)pc, hw);
         float g0, g1, g2;
         rng_normals3(pixel_hash(pc, key), g0, g1, g2);
         float cn0 = np[0] + g0 * normal_range;
@@ -100,13 +101,14 @@ AMVS_DEV uint32_t propagate_entry(int pc, unsigned buf_c, bool inb_c, unsigned b
     return (unsigned)pc | ((inb_c ? 1u : 0u) << 29) | (buf_n << 30) | (buf_c << 31);
 }
 
-AMVS_DEV void propagate_normals(const uint32_t *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, int noff)
+AMVS_DEV void propagate_normals(const uint32_t *nq, int head, int n, int lane, float *nbuf0, float *nbuf1, int noff, int hw)
 {
+    (void)hw;
     if (lane < n) {
         const uint32_t e = nq[(head + lane) & (2 * AMVS_WAVE - 1)];
-        const int pc = (int)(e & 0x1FFFFFFFu);
+        const int pc = AMVS_IDX((int)(e & 0x1FFFFFFFu), hw);
         const bool inb_c = (e >> 29) & 1u;
-        const int pn = inb_c ? pc + noff : 0;
+        const int pn = AMVS_IDX(inb_c ? pc + noff : 0, hw);
         // (three consecutive dwords each way: hipcc merges them into one dwordx3 access)
         const float *src = (((e >> 30) & 1u) ? nbuf1 : nbuf0) + 3ll * pn;
         const float t0 = src[0], t1 = src[1], t2 = src[2];

@@ -17,6 +17,7 @@
 //     buffers "in" and writes buffers "out", so strips never see half-updated maps.
 //   * block index -> strip mapping is XCD-aware: each of the 8 XCDs receives a contiguous
 //     range of strips so halos and source-image rows are shared in that XCD's L2.
+#define AMVS_TU_ID 1
 #include "amvs_exact_common.h"
 
 namespace amvs {
@@ -180,11 +181,11 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const float d_raw = d_in[inb ? pix + noff : 0];       // re-read by neighbours: cached
+        const float d_raw = d_in[AMVS_IDX(inb ? pix + noff : 0, HW)];       // re-read by neighbours: cached
         // ref gray: in the packed path the low byte of the row-pair map decoded through the table
         // (the same float as the float32 map holds, at half the bytes)
-        const float r_raw = U8 ? lut[AMVS_REF_CODE(live ? pix + PADW * yr : 0) & 0xFFu]
-                               : ref[live ? pix : 0];
+        const float r_raw = U8 ? lut[AMVS_REF_CODE(AMVS_IDX_LOHI(live ? pix + PADW * yr : 0, -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))) & 0xFFu]
+                               : ref[AMVS_IDX(live ? pix : 0, HW)];
 
         // ---- candidate depth of this (possibly halo) pixel ----
         // outside the image the pulled candidate is depth_min (F.pad value)
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
         const int yc = PAIR ? yr - dy * HALF : yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
-        const int pc = outl ? yc * W + xc : 0;
+        const int pc = AMVS_IDX(outl ? yc * W + xc : 0, HW);
         const float oldd_tagged = d_in[pc], oldc = cost_io[pc];
         const float oldd = depth_untag(oldd_tagged, a.depth_mask);
         const unsigned buf_c = depth_buffer(oldd_tagged);     // where this pixel's current normal lives
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
         // without an output pixel have pc = 0: they must not form pc + noff, which lies BEFORE the map
         // for the negative offsets of odd iterations.
         const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-        const int pn = (outl & inb_c) ? pc + noff : 0;
+        const int pn = AMVS_IDX((outl & inb_c) ? pc + noff : 0, HW);
         const float nb_tagged = mode == MODE_PROP ? d_in[pn] : 0.0f;
         // the centre pixel was sampled by lane+HALF, HALF rows ago
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);     // low S bits: row r-HALF
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -381,8 +382,8 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff, (int)HW);
             q_head += n;
         }
     }
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void sample_dump_kernel(const StepArgs a
     const long long HW = (long long)H * W;
     const int x = blockIdx.x * AMVS_WAVE + lane, y = blockIdx.y;
     const bool live = x < W;
-    const float d = a.d_in[live ? y * W + x : 0];
+    const float d = a.d_in[AMVS_IDX(live ? y * W + x : 0, HW)];
     JobCP jr = reload(job);
     const Vec3 Pw = backproject(jr->Kinv, jr->Rref, jr->tref, x, y, d);
     float v[S];
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__res
     for (int r = 0; r < rows; ++r) {
         const int yr = y0 - HALF + r;
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
-        const float rv = live ? img[yr * W + xr] : 0.0f;
+        const float rv = live ? img[AMVS_IDX(yr * W + xr, (long long)H * W)] : 0.0f;
 #pragma unroll
         for (int i = 0; i < K - 1; ++i) ring[i] = ring[i + 1];
         ring[K - 1] = rv;
@@ -497,8 +498,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void box_stats_kernel(const float *__res
         const int xc = xr + HALF, yc = yr - HALF;
         if (lane < OUTW && xc < W) {
             const float m = br * INV_AREA;
-            mo[yc * W + xc] = m;
-            vo[yc * W + xc] = brr * INV_AREA - m * m;
+            mo[AMVS_IDX(yc * W + xc, (long long)H * W)] = m;
+            vo[AMVS_IDX(yc * W + xc, (long long)H * W)] = brr * INV_AREA - m * m;
         }
     }
 }
@@ -521,8 +522,8 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict
         const int y = (int)(i / PW) - B, x = (int)(i % PW) - B;
         const bool xin = (unsigned)x < (unsigned)W;
         const bool in0 = xin & ((unsigned)y < (unsigned)H), in1 = xin & ((unsigned)(y + 1) < (unsigned)H);
-        const float g0 = in0 ? img[(long long)y * W + x] : 0.0f;
-        const float g1 = in1 ? img[(long long)(y + 1) * W + x] : 0.0f;
+        const float g0 = in0 ? img[AMVS_IDX((long long)y * W + x, (long long)H * W)] : 0.0f;
+        const float g1 = in1 ? img[AMVS_IDX((long long)(y + 1) * W + x, (long long)H * W)] : 0.0f;
         const int c0 = min(max((int)__builtin_rintf(g0 * 255.0f), 0), 255);
         const int c1 = min(max((int)__builtin_rintf(g1 * 255.0f), 0), 255);
         if (in0 & !((float)c0 / 255.0f == g0)) atomicOr(inexact, 1);
@@ -820,3 +821,5 @@ hipError_t launch_rng_fill(unsigned long long seed, unsigned view, unsigned draw
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(kernels)

@@ -18,9 +18,13 @@
 //     size as (mean1, var1) maps (launch_fast_stats): no ref sums, and no ref ring in LDS -- the
 //     last k reference codes of a column travel as packed bytes in 2-3 VGPRs;
 //   * NCC epilogue: cov * RN(1/den) (no quotient refinement).
+#define AMVS_TU_ID 2
 #include "amvs_fast_common.h"
 
 namespace amvs {
+
+// the reference view's packed map is addressed from its pixel (0,0): valid texel indices [-origin, elems - origin)
+#define AMVS_REF_PAIR_IDX(i) AMVS_IDX_LOHI((i), -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))
 
 template <int K, int S> struct StepLds {
     static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 4u;
@@ -117,14 +121,14 @@ __global__ __launch_bounds__(AMVS_WAVE * AMVS_WG_WAVES) void pm_sample_fast_kern
         const bool live = col_in;
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const float d_raw = d_in[inb ? pix + noff : 0];
+        const float d_raw = d_in[AMVS_IDX(inb ? pix + noff : 0, HW)];
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
         const float dc = candidate_depth(a, mode, inb, d_raw, h0);
         float v[S];
         const unsigned okbits = fast_sample_sources_checked<S, true>(job, fc, cols, (float)yr, dc, live, v);
         if (live) {
 #pragma unroll
-            for (int s = 0; s < S; ++s) out[s * HW + pix] = sample_encode(v[s], (okbits >> s) & 1u);
+            for (int s = 0; s < S; ++s) out[AMVS_IDX(s * HW + pix, S * HW)] = sample_encode(v[s], (okbits >> s) & 1u);
         }
     }
 }
@@ -189,6 +193,10 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     const JobCP job = (JobCP)(a.jobs + job_id);
     const int H = a.H, W = a.W, mode = MODE_T >= 0 ? MODE_T : a.mode;
     const long long HW = (long long)H * W;
+#ifdef AMVS_CHECK_SELFTEST
+    // (proof that the index-checked build reports: one deliberately out-of-range index per launch, never dereferenced)
+    if (blockIdx.x == 0 && threadIdx.x == 0) (void)AMVS_IDX(HW + 7, HW);
+#endif
     constexpr int PADW = 2 * AMVS_PAIR_BORDER;
     // (global address space: a generic pointer would make these FLAT loads, which force vmcnt(0) and
     // lgkmcnt(0) waits)
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
         const bool live = col_in & ((unsigned)yr < (unsigned)H);
         const bool inb = live & ((unsigned)(yr + oy) < (unsigned)H) & ((unsigned)(xr + ox) < (unsigned)W);
         const int pix = yr * W + xr;
-        const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
+        const uint32_t rc_raw = ref_pairs[AMVS_REF_PAIR_IDX(live ? pix + PADW * yr : 0)];
         const uint32_t h0 = pixel_hash((uint32_t)pix, key);
         float v[S];
         unsigned okbits = 0u;
@@ -274,7 +282,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
                 v[s] = s < NL ? lring_p[(s * K + pslot) * AMVS_WAVE + lane] : xp[(s < NL ? 0 : s - NL) * AMVS_WAVE + lane];
             pslot = pslot == 0 ? K - 1 : pslot - 1;
         } else if constexpr (PRE) {
-            const uint32_t *__restrict__ sp = smp + (live ? pix : 0);
+            const uint32_t *__restrict__ sp = smp + AMVS_IDX(live ? pix : 0, HW);
             uint32_t w[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) w[s] = sp[s * HW];
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
             }
         } else {
             // ---- candidate depth of this (possibly halo) pixel: as in the exact kernel ----
-            const float d_raw = d_in[inb ? pix + noff : 0];
+            const float d_raw = d_in[AMVS_IDX(inb ? pix + noff : 0, HW)];
             const float dc = candidate_depth(a, mode, inb, d_raw, h0);
             okbits = fast_sample_sources_checked<S, true, true>(job, fc, cols, (float)yr, dc, live, v);
             if constexpr (PAIR) {
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
         const int yc = PAIR ? yr - dy * HALF : yr - HALF;
         const int xc = xr + HALF;
         const bool outl = (lane < OUTW) & (xc < W);
-        const int pc = outl ? yc * W + xc : 0;
+        const int pc = AMVS_IDX(outl ? yc * W + xc : 0, HW);
         const float oldd_tagged = d_in[pc], oldc = cost_io[pc];
         const float oldd = depth_untag(oldd_tagged, a.depth_mask);
         const unsigned buf_c = depth_buffer(oldd_tagged);     // where this pixel's current normal lives
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
         // without an output pixel have pc = 0: they must not form pc + noff, which lies BEFORE the map
         // for the negative offsets of odd iterations.
         const bool inb_c = ((unsigned)(yc + oy) < (unsigned)H) & ((unsigned)(xc + ox) < (unsigned)W);
-        const int pn = (outl & inb_c) ? pc + noff : 0;
+        const int pn = AMVS_IDX((outl & inb_c) ? pc + noff : 0, HW);
         const float nb_tagged = mode == MODE_PROP ? d_in[pn] : 0.0f;
         const f32x2_t mv1 = ref_stats[pc];
         const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = propagate_entry(pc, buf_c, inb_c, depth_buffer(nb_tagged));
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff);
+                    propagate_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, noff, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
                 if (better) nq[(q_tail + rank) & (NQ - 1)] = refine_entry(pc, buf_c);
                 q_tail += __popcll(won);
                 if (q_tail - q_head >= AMVS_WAVE) {
-                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key);
+                    refine_normals(nq, q_head, AMVS_WAVE, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
                     q_head += AMVS_WAVE;
                 }
             }
@@ -410,8 +418,8 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     if (mode == MODE_REFINE || mode == MODE_PROP) {
         while (q_tail - q_head > 0) {
             const int n = min(q_tail - q_head, AMVS_WAVE);
-            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key);
-            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff);
+            if (mode == MODE_REFINE) refine_normals(nq, q_head, n, lane, nbuf0, nbuf1, a.normal_range, key, (int)HW);
+            else propagate_normals(nq, q_head, n, lane, nbuf0, nbuf1, noff, (int)HW);
             q_head += n;
         }
     }
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void sample_dump_fast_kernel(const StepA
     const long long HW = (long long)H * W;
     const int x = blockIdx.x * AMVS_WAVE + threadIdx.x, y = blockIdx.y;
     const bool live = x < W;
-    const float d = a.d_in[live ? y * W + x : 0];
+    const float d = a.d_in[AMVS_IDX(live ? y * W + x : 0, HW)];
     float v[S];
     unsigned okbits;
     FastCol cols[S];
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(256) void fast_stats_kernel(const uint16_t *__restr
             for (int dx = -HALF; dx <= HALF; ++dx) {
                 const int xx = x + dx;
                 if ((unsigned)xx >= (unsigned)W) continue;
-                const int c = pairs[(long long)(yy + B) * PW + xx + B] & 0xFF;
+                const int c = pairs[AMVS_IDX((long long)(yy + B) * PW + xx + B, (long long)(H + 2 * B) * PW)] & 0xFF;
                 sr += c; srr += c * c;
             }
         }
@@ -655,3 +663,5 @@ hipError_t launch_sample_fast(int S, const StepArgs &a, hipStream_t st)
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(kernels_fast)

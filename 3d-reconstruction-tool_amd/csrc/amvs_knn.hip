@@ -16,6 +16,8 @@
 // <= (r*h)^2 (everything not yet visited is farther); a query left pending gets one block that scans
 // the box of cells within R = 4, 8, 16, ... shells cooperatively (knn_box_kernel) until the same rule
 // holds or the box is the whole grid.
+#define AMVS_TU_ID 8
+#include "amvs_check.h"
 #include "amvs_kernels.h"
 
 #include <hipcub/hipcub.hpp>
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void knn_count_kernel(const double *__restrict
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const int cx = cell_of(gr, pts[3 * i], 0), cy = cell_of(gr, pts[3 * i + 1], 1), cz = cell_of(gr, pts[3 * i + 2], 2);
-        const int c = (cz * gr.g[1] + cy) * gr.g[0] + cx;
+        const int c = AMVS_IDX((cz * gr.g[1] + cy) * gr.g[0] + cx, (long long)gr.g[0] * gr.g[1] * gr.g[2]);
         cell[i] = c;
         atomicAdd(&count[c], 1);
     }
@@ -73,12 +75,12 @@ __global__ __launch_bounds__(256) void knn_count_kernel(const double *__restrict
 __global__ __launch_bounds__(256) void knn_place_kernel(const double *__restrict__ pts, long long n,
                                                         const int *__restrict__ cell, const int *__restrict__ start,
                                                         int *__restrict__ cursor, double *__restrict__ sorted,
-                                                        int *__restrict__ origin)
+                                                        int *__restrict__ origin, long long cells)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c = cell[i];
-        const int slot = start[c] + atomicAdd(&cursor[c], 1);
+        const int c = AMVS_IDX(cell[i], cells);
+        const int slot = AMVS_IDX(start[c] + atomicAdd(&cursor[c], 1), n);
         sorted[3 * (long long)slot] = pts[3 * i];
         sorted[3 * (long long)slot + 1] = pts[3 * i + 1];
         sorted[3 * (long long)slot + 2] = pts[3 * i + 2];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
 {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
-    const int self = origin[q];
+    const int self = AMVS_IDX(origin[q], n);
     if (!pending[self]) return;
     const double qx = sorted[3 * q], qy = sorted[3 * q + 1], qz = sorted[3 * q + 2];
     const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
     double worst = __builtin_inf();
 
     auto visit_cell = [&](int x, int y, int z) {
-        const int c = (z * gr.g[1] + y) * gr.g[0] + x;
-        const int b = start[c], e = start[c + 1];
+        const int c = AMVS_IDX((z * gr.g[1] + y) * gr.g[0] + x, (long long)gr.g[0] * gr.g[1] * gr.g[2]);
+        const int b = AMVS_IDX(start[c], n + 1), e = AMVS_IDX(start[c + 1], n + 1);
         for (int p = b; p < e; ++p) {
             const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
                          dz = qz - sorted[3 * (long long)p + 2];
@@ -209,9 +211,9 @@ template <int K>
 __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__ pts, const double *__restrict__ sorted,
                                                       Grid gr, const int *__restrict__ start, int r_first,
                                                       const int *__restrict__ queries, unsigned char *__restrict__ pending,
-                                                      double *__restrict__ mean_out)
+                                                      double *__restrict__ mean_out, long long n)
 {
-    const int self = queries[blockIdx.x];
+    const int self = AMVS_IDX(queries[blockIdx.x], n);
     const double qx = pts[3 * (long long)self], qy = pts[3 * (long long)self + 1], qz = pts[3 * (long long)self + 2];
     const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -231,7 +233,9 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
         for (int row = wave; row < rows; row += 4) {
             const int z = z0 + row / ny, y = y0 + row % ny;
             const long long base = ((long long)z * gr.g[1] + y) * gr.g[0];
-            const int b = start[base + x0], e = start[base + x1 + 1];
+            const long long cells1 = (long long)gr.g[0] * gr.g[1] * gr.g[2] + 1;       // entries of `start`
+            (void)cells1;
+            const int b = AMVS_IDX(start[AMVS_IDX(base + x0, cells1)], n + 1), e = AMVS_IDX(start[AMVS_IDX(base + x1 + 1, cells1)], n + 1);
             for (int p = b + lane; p < e; p += 64) {
                 const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
                              dz = qz - sorted[3 * (long long)p + 2];
@@ -302,10 +306,10 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
 
 template <int K>
 hipError_t launch_box(const double *pts, const double *sorted, const Grid &gr, const int *start, int r_first,
-                      const int *queries, int n_queries, unsigned char *pending, double *mean_out, hipStream_t st)
+                      const int *queries, int n_queries, unsigned char *pending, double *mean_out, long long n, hipStream_t st)
 {
     hipLaunchKernelGGL((knn_box_kernel<K>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, sorted, gr, start, r_first,
-                       queries, pending, mean_out);
+                       queries, pending, mean_out, n);
     return hipGetLastError();
 }
 
@@ -460,7 +464,7 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     auto query = [&](int max_shells) -> hipError_t {
         KCHK(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));     // reused as the placement cursor
         hipLaunchKernelGGL(knn_place_kernel, dim3(bx), dim3(256), 0, st, d_pts, n, d_cell, d_start, d_count,
-                           d_sorted, d_origin);
+                           d_sorted, d_origin, cells);
         KCHK(hipGetLastError());
         switch (k) {
         case 8: return launch_query<8>(d_sorted, n, gr, d_start, d_origin, d_pending, max_shells, d_mean, st);
@@ -526,11 +530,11 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
             hipError_t e = hipErrorInvalidValue;
             const int r_first = 2 * KNN_SHELLS;
             switch (k) {
-            case 8: e = launch_box<8>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
-            case 10: e = launch_box<10>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
-            case 16: e = launch_box<16>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
-            case 20: e = launch_box<20>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
-            case 32: e = launch_box<32>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, st); break;
+            case 8: e = launch_box<8>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
+            case 10: e = launch_box<10>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
+            case 16: e = launch_box<16>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
+            case 20: e = launch_box<20>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
+            case 32: e = launch_box<32>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
             default: break;
             }
             KCHK_D(e);
@@ -555,3 +559,5 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(knn)

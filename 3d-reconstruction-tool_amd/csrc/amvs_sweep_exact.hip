@@ -28,6 +28,7 @@
 // 3 / 4 / 1 source rings in LDS instead of 2: 46.7 / 44.7 / 47.7; max-ilp scheduler 45.8; strips of 24 / 20
 // rows 46.8 / 46.6; 16 / 22 planes per wave 45.9 / 44.2 (automatic: 13).
 #define AMVS_RELOAD_STRIDE 2
+#define AMVS_TU_ID 4
 #include "amvs_exact_common.h"
 
 namespace amvs {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
 
     for (int d = d_begin; d < d_end; ++d) {
-        const float depth = a.depths[d];
+        const float depth = a.depths[AMVS_IDX(d, a.D)];
         float ring_r[K];
         float ring_v[Ring<S>::NR][K];
         typename Hist<K, S>::T hist_ok = 0;
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const int pix = yr * W + xr;
             // ref gray: in the packed path the low byte of the row-pair map decoded through the table (the
             // same float as the float32 map holds, at half the bytes)
-            const float rvl = U8 ? lut[ref_pairs[live ? pix + PADW * yr : 0] & 0xFFu] : ref[live ? pix : 0];
+            const float rvl = U8 ? lut[ref_pairs[AMVS_IDX_LOHI(live ? pix + PADW * yr : 0, -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))] & 0xFFu]
+                                 : ref[AMVS_IDX(live ? pix : 0, HW)];
             const float rv = live ? rvl : 0.0f;
             JobCP jr = reload(job);
             const Vec3 Pw = backproject_cols(jr->Kinv, jr->Rref, jr->tref, rc, yr, depth);
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
             const int yc = yr - HALF;
             const int xc = xr + HALF;
             const bool outl = (lane < OUTW) & (xc < W);
-            const int pc = outl ? yc * W + xc : 0;
+            const int pc = AMVS_IDX(outl ? yc * W + xc : 0, HW);
             // mean1 / var1 of the reference window (precomputed: box_stats_kernel forms the sums this kernel
             // used to form per plane, in the same order)
             const float m1 = ref_mean[pc], v1 = ref_var[pc];
@@ -251,20 +253,20 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
         for (int i = 0; i < trows; ++i) {
             const uint32_t b = best[i][lane];
             const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
+            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], ((b >> 12) << 16) | (65535u - plane));
         }
 }
 
 // decode the merged keys: depth of the winning plane (dense_stereo.py:310) and its vote count
 __global__ __launch_bounds__(256) void plane_sweep_finish_kernel(const unsigned *__restrict__ keys,
-                                                                 const float *__restrict__ depths, long long n,
+                                                                 const float *__restrict__ depths, int n_planes, long long n,
                                                                  float *__restrict__ depth_out,
                                                                  float *__restrict__ conf_out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const unsigned b = keys[i];
-        depth_out[i] = depths[65535 - (int)(b & 0xFFFFu)];
+        depth_out[i] = depths[AMVS_IDX(65535 - (int)(b & 0xFFFFu), n_planes)];
         conf_out[i] = (float)(b >> 16);
     }
 }
@@ -310,9 +312,11 @@ hipError_t launch_sweep_finish(const SweepArgs &a, hipStream_t st)
 {
     const long long n = (long long)a.n_jobs * a.H * a.W;
     const int bx = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(plane_sweep_finish_kernel, dim3(bx), dim3(256), 0, st, a.keys, a.depths, n, a.depth_out,
+    hipLaunchKernelGGL(plane_sweep_finish_kernel, dim3(bx), dim3(256), 0, st, a.keys, a.depths, a.D, n, a.depth_out,
                        a.conf_out);
     return hipGetLastError();
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(sweep_exact)

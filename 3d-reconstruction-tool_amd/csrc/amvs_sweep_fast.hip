@@ -4,6 +4,7 @@
 // iterative scheduler (-mllvm -amdgpu-sched-strategy=iterative-maxocc, csrc/Makefile) measured +1.7 % on it
 // (69.3-69.7 against 67.9-68.7 G px-hyp/s, four alternations in one run), -0.5 % on the sweep step.  The
 // instruction order changes, the operations do not (-ffp-contract=off, explicit fmaf): same bits.
+#define AMVS_TU_ID 3
 #include "amvs_fast_common.h"
 
 namespace amvs {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const float fy_first = (float)(y0 - HALF), fy_last = (float)(y0 - HALF + rows - 1);
 
     for (int d = d_begin; d < d_end; ++d) {
-        const float depth = a.depths[d];
+        const float depth = a.depths[AMVS_IDX(d, a.D)];
         bool lean_ok = true;
         {
             JobCP jr = reload(job);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             const int yr = y0 - HALF + r;
             const bool live = col_in & ((unsigned)yr < (unsigned)H);
             const int pix = yr * W + xr;
-            const uint32_t rc_raw = ref_pairs[live ? pix + PADW * yr : 0];
+            const uint32_t rc_raw = ref_pairs[AMVS_IDX_LOHI(live ? pix + PADW * yr : 0, -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))];
             const uint32_t rcode = live ? (rc_raw & 0xFFu) : 0u;
             float v[S];
             bool unused_ok = true;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
             const int yc = yr - HALF;
             const int xc = xr + HALF;
             const bool outl = (lane < OUTW) & (xc < W);
-            const f32x2_t mv1 = ref_stats[outl ? yc * W + xc : 0];
+            const f32x2_t mv1 = ref_stats[AMVS_IDX(outl ? yc * W + xc : 0, HW)];
             const unsigned okc = (unsigned)__shfl_down((int)(unsigned)hist_ok, HALF);
             float rr[K];
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
         for (int i = 0; i < trows; ++i) {
             const uint32_t b = best[i][lane];
             const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[(y0 + i) * W + xc], ((b >> 12) << 16) | (65535u - plane));
+            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], ((b >> 12) << 16) | (65535u - plane));
         }
 }
 
@@ -201,3 +202,5 @@ hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st)
 }
 
 }  // namespace amvs
+
+AMVS_CHECK_TU(sweep_fast)

@@ -32,6 +32,7 @@ extern "C" {
 #define AMVS_OK            0
 #define AMVS_EINVAL       -1   /* bad argument                                  */
 #define AMVS_EHIP         -2   /* HIP runtime error (no device, OOM, launch)    */
+#define AMVS_EINDEX       -4   /* index-checked build only: a kernel formed an out-of-range index (amvs_index_check) */
 #define AMVS_EUNSUPPORTED -3   /* patch size (even, or above 31) / source count outside [2, 6] / k of the kNN */
 
 typedef struct amvs_ctx amvs_ctx;
@@ -372,6 +373,17 @@ int amvs_comm_destroy(amvs_ctx *ctx);
  * bytes as the reference writes, through one buffered native writer (no GPU involved; ctx-free).
  * points: n x 3 float64, colors: n x 3 int64 (the reference casts with .astype(int)).          */
 int amvs_write_ply(const char *path, const double *points, const int64_t *colors, int64_t n);
+
+/* Index-checked build (csrc/amvs_check.h, -DAMVS_CHECK_INDICES; amvs_version() then ends in "+index-checks"): the
+ * GPU-side substitute for an address sanitizer, which this pool does not offer for device code.  Every
+ * data-dependent global index of the sweep, plane-sweep, extended, fusion and neighbour-search kernels is compared
+ * with its buffer's extent before the access; a violation is counted, the first is recorded and the access
+ * redirected to a safe index.  report[0] = violations since the last reset, report[1] = translation unit << 32 |
+ * source line of the first, report[2] = its index, report[3] = the extent; amvs_sync, amvs_patchmatch,
+ * amvs_plane_sweep and amvs_fetch_cloud return AMVS_EINDEX while a violation is on record.  The shipped build
+ * compiles the checks away: it reports zeros.  (The reference has no counterpart; test infrastructure of the
+ * device code.)                                                                                             */
+int amvs_index_check(uint64_t report[4], int reset);
 
 /* Self test: the kernels replace the IEEE divide / sqrt expansions by v_rcp_f32 / v_rsq_f32 with
  * FMA corrections (plus an IEEE path for out-of-range operands).  Compares both against

@@ -117,3 +117,19 @@ def chamfer(a, b):
 E2E_MIN_FRACTION = 0.98
 CONF_HIST_TOL = 0.01
 CHAMFER_TOL = 1e-3
+
+
+@pytest.fixture(autouse=True)
+def _no_index_violations(request):
+    """With an index-checked build of libamvs (AMVS_LIB=build/variants/libamvs_check.so; csrc/amvs_check.h) every
+    GPU test also asserts that no kernel formed an out-of-range global index -- the device-side substitute for an
+    address sanitizer.  With the shipped library this is a no-op."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    from amvs import _lib
+    if not _lib.index_checks_enabled():
+        return
+    count, tu, line, index, extent = _lib.index_check(reset=True)
+    assert count == 0, (f"{count} out-of-range global accesses; first in translation unit {tu} line {line}: "
+                        f"index {index}, extent {extent}")
