@@ -85,11 +85,12 @@ AMVS_DEV unsigned sweep_sample_sources(JobCP job, const SampleConsts &sc, const 
 //     ncc > t  <=>  cov > 0  and  cov^2 > t^2 x        (x > 0, real arithmetic)
 // The evaluated ncc carries two roundings (square root, correctly rounded quotient: relative 1.2e-7), the
 // evaluated cov^2 and t^2 x three (1.8e-7); a margin of 1e-6 on t^2 x separates the sure cases:
-//     sure_yes:  cov > 0, 1e-12 <= x < 1e30, 1e30 > cov^2 > t^2 x (1 + 1e-6)
-//     sure_no :  cov <= 0 (the quotient is <= 0, -inf or NaN: never > t > 0)
-//                or cov > 0, 1e-12 <= x < 1e30, cov^2 < t^2 x (1 - 1e-6)
+//     sure_yes:  cov > 0, 1e-12 <= x < 1e30, 1e30 > cov^2 > t^2 x (1 + 1e-6)   (the upper bound on cov^2 keeps the
+//                quotient's intermediate products finite: qdiv of an overflowing cov / den is NaN, not a vote)
+//     sure_no :  not (cov > 0): the quotient is <= 0, -inf or NaN (a NaN cov included): never > t > 0
+//                or 1e-12 <= x < 1e30, cov^2 < t^2 x (1 - 1e-6)
 // (the bounds on x keep t^2 x a normal, finite number for 2^-10 <= t < 2^10; a cov^2 that underflows is far
-//  below any such t^2 x; NaN operands fail every comparison and stay undecided.)  Everything else -- a measure-zero band around the
+//  below any such t^2 x; a NaN x fails both bounds and, for cov > 0, stays undecided.)  Everything else -- a measure-zero band around the
 // threshold, negative or tiny x, non-finite values -- is undecided and makes the wave evaluate the vote itself.
 struct VoteGate { float t2_hi, t2_lo; bool usable; };
 
@@ -208,18 +209,20 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
                 covs[s] = brvs[s] * INV_AREA - m1 * mean2;
                 xs[s] = v1 * var2 + 1e-8f;
             }
-            uint32_t votes = 0u;
-            bool decided = gate.usable;
+            // (bit s of yes_bits / open_bits: source s votes for sure / is undecided; an invalid projection casts no
+            //  vote whatever the NCC, so both are masked with the validity bits at the end)
+            uint32_t yes_bits = 0u, open_bits = 0u;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const float c2 = covs[s] * covs[s];
                 const bool pos = covs[s] > 0.0f, xok = (xs[s] >= 1e-12f) & (xs[s] < 1e30f);
                 const bool yes = pos & xok & (c2 > gate.t2_hi * xs[s]) & (c2 < 1e30f);
-                const bool no = (covs[s] <= 0.0f) | (pos & xok & (c2 < gate.t2_lo * xs[s]));
-                const bool oks = (okc >> s) & 1u;
-                decided &= yes | no | !oks;                  // (an invalid projection casts no vote whatever the NCC)
-                votes += (yes & oks) ? 1u : 0u;
+                const bool no = !pos | (xok & (c2 < gate.t2_lo * xs[s]));
+                yes_bits |= yes ? (1u << s) : 0u;
+                open_bits |= (yes | no) ? 0u : (1u << s);
             }
+            uint32_t votes = (uint32_t)__builtin_popcount(yes_bits & okc & ((1u << S) - 1u));
+            const bool decided = gate.usable & ((open_bits & okc) == 0u);
             if (__builtin_expect(!__all(decided | !outl), 0)) {
                 // some lane is inside the margin (or the threshold is outside the gate's range): the vote as
                 // the reference forms it, for the whole wave

@@ -70,21 +70,32 @@ def profiled_traffic(kernel_key, workload_key):
     with tools/gather_rate.hip (one dword per 128 bytes moves as many bytes as one per 64 bytes, and
     TCC_MISS_sum x 64 B reproduces FETCH_SIZE).  None if no profile of this exact workload AND of the
     kernel sources in this tree (kernel_source_hash) is committed."""
+    return profiled_traffic_and_source(kernel_key, workload_key)[0]
+
+
+def profiled_traffic_and_source(kernel_key, workload_key):
+    """(bytes per launch, the committed summary they come from) -- the bench line names the file
+    (`roofline.traffic_source`): the figure is REPLAYED from a builder-side rocprofv3 run of the same kernel
+    sources on the same workload, not measured inside the driver's run."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
         e = t.get(kernel_key)
         if e and e.get("workload") == workload_key and e.get("source_hash") == kernel_source_hash(kernel_key):
-            return int((e["fetch_kib"] * e.get("fetch_correction", 1.0) + e["write_kib"]) * 1024)
+            return (int((e["fetch_kib"] * e.get("fetch_correction", 1.0) + e["write_kib"]) * 1024),
+                    "profiles/%s.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2; replayed, hash-checked "
+                    "against the kernel sources)" % e.get("source", "?"))
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 # Issue cost of one VALU wave-instruction per SIMD, measured on MI355X at 8 waves per SIMD with
-# tools/valu_rate.hip (gpurun_out/r2_valu_rate.log): v_add_f32 / v_fma_f32 0.95-1.16 ns, v_add_f32_dpp
-# wave_shl:1 (the row sums' cross-lane adds) 3.26 ns.  1 024 SIMDs per MI355X.
+# tools/valu_rate.hip (profiles/r04_logs/valu_rate.log): v_add_f32 / v_fma_f32 0.95-1.16 ns, v_add_f32_dpp
+# wave_shl:1 (the row sums' cross-lane adds) 3.26 ns.  1 024 SIMDs per MI355X.  These are the BUILDER'S
+# microbenchmark figures (a reading aid, not an independent bound): the line names their source.
 VALU_PLAIN_NS, VALU_DPP_NS, N_SIMDS = 0.95, 3.26, 1024
+ISSUE_NS_SOURCE = "tools/valu_rate.hip on MI355X, 8 waves per SIMD (profiles/r04_logs/valu_rate.log)"
 
 
 def valu_issue_roofline(kernel_key, workload_key, dpp_insts, launch_ms):
@@ -104,7 +115,7 @@ def valu_issue_roofline(kernel_key, workload_key, dpp_insts, launch_ms):
     plain = max(valu - dpp_insts, 0.0)
     floor_ms = (plain * VALU_PLAIN_NS + dpp_insts * VALU_DPP_NS) / N_SIMDS * 1e-6
     return {"bound": "valu-issue", "valu_wave_instructions_per_launch": int(valu), "of_which_dpp": int(dpp_insts),
-            "issue_ns": {"plain": VALU_PLAIN_NS, "dpp": VALU_DPP_NS}, "simds": N_SIMDS,
+            "issue_ns": {"plain": VALU_PLAIN_NS, "dpp": VALU_DPP_NS}, "issue_ns_source": ISSUE_NS_SOURCE, "simds": N_SIMDS,
             "floor_ms": round(floor_ms, 3), "frac": round(floor_ms / launch_ms, 3) if launch_ms > 0 else None}
 
 
@@ -238,6 +249,8 @@ def main():
                     help="N>1: strong = fixed --scene-views scene split over the ranks; weak = --views-per-gpu each")
     ap.add_argument("--scene-views", type=int, default=32, help="views of the fixed scene for N>1 (BASELINE config 4)")
     ap.add_argument("--no-planesweep", action="store_true", help="skip the plane-sweep sub-record")
+    ap.add_argument("--no-subrecords", action="store_true",
+                    help="skip the `exact` (configs 3 and 2 in the classes' default arithmetic) and `cli_defaults` sub-records")
     ap.add_argument("--fusion", action="store_true",
                     help="fuse + filter the gathered maps inside every timed step (BASELINE config 5)")
     ap.add_argument("--gather-per-iteration", action="store_true",
@@ -258,6 +271,7 @@ def main():
         sys.exit(launch_ranks(args.gpus))
     if args.config5:
         args.height, args.width, args.scene_views, args.fusion, args.no_planesweep = 2160, 3840, 64, True, True
+        args.no_subrecords = True
         if args.gpus == 1:
             args.views_per_gpu = 64
     if args.workload == "planesweep":
@@ -603,6 +617,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": profiled_traffic(kname, f"{vpl}x{W}x{H}"),
+                         "traffic_source": profiled_traffic_and_source(kname, f"{vpl}x{W}x{H}")[1],
                          "algorithmic_bytes_per_launch": algo_bytes_launch,
                          "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches},
             "confidence_ms_per_step": round(conf_ms / args.steps, 3),
@@ -657,9 +672,170 @@ def main():
             # takes) before the 10 timed ones -- after a single 7 ms step the device is still ramping
             # (launches under the tracer: 7.46 7.01 6.68 6.39 6.37 6.35 ms, profiles/r03_plane_sweep_fast.txt)
             out["planesweep"] = run_planesweep(args, steps=10, warmup=8, with_cpu=not args.no_cpu_baseline, cpu_reps=3)
+            if not args.no_subrecords and args.mode == "fast":
+                # what a drop-in user runs: the classes default to the EXACT arithmetic (core/mvs_patchmatch.py,
+                # core/dense_stereo.py) -- config 3 and config 2 in it -- and the reference's CLI constructs
+                # PatchMatchMVS(scale=0.25, num_iterations=3, min_views=3), i.e. patch 11, 3 x (2 + 8)
+                exact_args = argparse.Namespace(**dict(vars(args), mode="exact"))
+                out["exact"] = {"patchmatch": run_patchmatch_single(sc, sources, ids, H, W, "exact", args.patch, args.iters,
+                                                                    args.samples, steps=5, warmup=2),
+                                "planesweep": run_planesweep(exact_args, steps=10, warmup=8, with_cpu=False)}
+                out["cli_defaults"] = run_cli_defaults()
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+def run_patchmatch_single(sc, sources, ids, H, W, mode, patch, iters, samples, steps, warmup):
+    """The one-GPU PatchMatch measurement of the main line (whole batch resident, K timed steps, the sweep
+    kernel's roofline from amvs_get_timing) for another arithmetic mode / patch size on the scene the main
+    line rendered (sc.grays hold the 8-bit-exact host images by now)."""
+    import torch
+
+    import amvs
+    from amvs.engine import make_pm_params
+    dev = torch.device("cuda", 0)
+    n = len(ids)
+    eng = amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), device=0, mode=mode)
+    stream = torch.cuda.Stream(device=dev)
+    eng.set_stream(stream.cuda_stream)
+    for i in ids:
+        eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+    params = make_pm_params(patch, iters, samples, sc.depth_min, sc.depth_max)
+    depth = torch.empty((n, H * W), dtype=torch.float32, device=dev)
+    normal = torch.empty((n, 3 * H * W), dtype=torch.float32, device=dev)
+    conf = torch.empty((n, H * W), dtype=torch.float32, device=dev)
+    srcs = [sources[r] for r in ids]
+    torch.cuda.synchronize()
+
+    def step():
+        eng.patchmatch_device(ids, srcs, params, 42, depth.data_ptr(), normal.data_ptr(), conf.data_ptr())
+        eng.sync()
+
+    gc.collect()
+    gc.disable()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep_ms, launches = 0.0, 0
+    for _ in range(steps):
+        step()
+        t = eng.timing()
+        sweep_ms += t["sweep_ms"]
+        launches += t["sweep_launches"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    S = len(srcs[0])
+    n_hyp = n * H * W * iters * (2 + samples)
+    vpl = eng.last_views_per_launch()
+    kname = ("pm_step_fast_kernel" if mode == "fast" else "pm_step_kernel") + f"<{patch},{S}>"
+    launch_ms = sweep_ms / max(launches, 1)
+    algo = (4 * S + 44) * vpl * H * W
+    achieved = algo / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    traffic, source = profiled_traffic_and_source(kname, f"{vpl}x{W}x{H}")
+    rec = {"metric": "Mpixel-hypotheses/s (PatchMatch sweep)", "value": round(n_hyp * steps / elapsed / 1e6, 1), "unit": "Mpx-hyp/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 2),
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{n}-view {W}x{H} PatchMatch MVS, {iters} iters x (2+{samples}) hypotheses, {patch}x{patch} NCC, "
+                                  f"{S} sources, {mode} arithmetic", "arithmetic": mode, "sampling": eng.sampling_mode(),
+                      "tile_rows": eng.last_tile_rows(), "views_per_launch": vpl, "pixel_hypotheses_per_step": n_hyp},
+           "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+                        "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(launch_ms, 4), "launches_timed": launches}}
+    eng.close()
+    return rec
+
+
+def run_cli_defaults(n_views=16, h=3024, w=4032):
+    """What the reference's CLI runs (run_reconstruction.py:131-136): PatchMatchMVS(camera, scale=0.25,
+    num_iterations=3, min_views=3) -- patch 11, 3 x (2 + 8), 4 sources, the classes' default (exact) arithmetic --
+    on 16 views of 4032x3024 (12 MP; processed at 1008x756), END TO END through PatchMatchMVS.reconstruct and
+    utils.save_ply: 8-bit BGR uploads + image preparation on the device, depth range, source selection, sweep,
+    fusion + filter on the device, PLY file.  The timed call is the second one (the first pays the one-off
+    allocations and the first-use compilation of nothing -- there is no JIT -- but the page-in of the library);
+    the split is measured on a third pass through the class's own steps."""
+    import contextlib
+    import tempfile
+
+    import torch
+
+    import amvs
+    from amvs.core import utils as amvs_utils
+    from amvs.synthetic import make_scene
+    dev = torch.device("cuda", 0)
+    scale = 0.25
+    H, W = int(h * scale), int(w * scale)
+    small = make_scene(n_views, H, W, seed=4321, device=str(dev))
+    ids = sorted(small.poses)
+    # 12-MP inputs: every processed pixel replicated 4 x 4 (the resize then returns the processed image itself)
+    images = [{"image": np.ascontiguousarray(np.repeat(np.repeat(small.colors[i], 4, axis=0), 4, axis=1))} for i in ids]
+    K = small.camera.K.copy()
+    K[:2] *= 1.0 / scale
+    cam = amvs.Camera(K=K, dist=np.zeros(5))
+    sink = open(os.devnull, "w")
+    with contextlib.redirect_stdout(sink):                     # (reconstruct prints the reference's progress lines)
+        pm = amvs.PatchMatchMVS(cam, scale=scale, num_iterations=3, min_views=3, seed=1)
+        tmp = tempfile.mkdtemp(prefix="amvs_bench_")
+        ply = os.path.join(tmp, "cloud.ply")
+        timings = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pts, cols = pm.reconstruct(images, small.poses)
+            t1 = time.perf_counter()
+            amvs_utils.save_ply(pts, cols, ply)
+            timings.append((t1 - t0, time.perf_counter() - t1))
+        # the split, through the class's own steps
+        t0 = time.perf_counter()
+        pm._estimate_depth_range(small.poses, None)
+        proc = pm._prepare_images_device(images, ids, small.poses)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        jobs = [(r, pm._select_source_views(r, ids, small.poses, k=pm.NUM_SOURCES)) for r in ids]
+        res = pm._sweep_resident(torch, jobs, proc, small.poses, ids)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        pts2, cols2, raw = pm._fuse_filter_resident(res, proc, small.poses)
+        t3 = time.perf_counter()
+    sink.close()
+    tm = pm.last_timing
+    eng = pm._engine
+    vpl, S = eng.last_views_per_launch(), pm.NUM_SOURCES
+    kname = f"pm_step_kernel<{pm.patch_size},{S}>"
+    launch_ms = tm["sweep_ms"] / max(tm["sweep_launches"], 1)
+    algo = (4 * S + 44) * vpl * H * W
+    achieved = algo / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    n_hyp = n_views * H * W * pm.num_iterations * (2 + pm.num_samples)
+    traffic, source = profiled_traffic_and_source(kname, f"{vpl}x{W}x{H}")
+    size = os.path.getsize(ply)
+    rec = {"workload": f"run_reconstruction.py defaults: PatchMatchMVS(scale=0.25, patch 11, 3 iters x (2+8), min_views 3), "
+                       f"{n_views} views of {w}x{h} processed at {W}x{H}, exact arithmetic, reconstruct() + save_ply end to end",
+           "end_to_end_s": round(sum(timings[1]), 4), "first_call_s": round(sum(timings[0]), 4),
+           "reconstruct_s": round(timings[1][0], 4), "save_ply_s": round(timings[1][1], 4),
+           "split_s": {"upload_and_image_preparation": round(t1 - t0, 4), "sweep": round(t2 - t1, 4),
+                       "fusion_and_filter": round(t3 - t2, 4)},
+           "sweep": {"metric": "Mpixel-hypotheses/s (PatchMatch sweep)",
+                     "value": round(n_hyp / max(tm["sweep_ms"], 1e-9) / 1e3, 1), "unit": "Mpx-hyp/s",
+                     "sweep_kernels_ms": round(tm["sweep_ms"], 3), "init_ms": round(tm["init_ms"], 3),
+                     "confidence_ms": round(tm["confidence_ms"], 3), "pixel_hypotheses": n_hyp,
+                     "tile_rows": eng.last_tile_rows(), "views_per_launch": vpl},
+           "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+                        "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(launch_ms, 4),
+                        "launches_timed": int(tm["sweep_launches"])},
+           "dense_points": {"raw": int(raw), "final": int(len(pts)), "points_per_s": round(len(pts) / max(sum(timings[1]), 1e-9), 1),
+                            "ply_bytes": size},
+           "input_bytes_uploaded": int(n_views * h * w * 3)}
+    assert len(pts2) == len(pts)
+    eng.close()
+    try:
+        os.remove(ply)
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    return rec
 
 
 def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
@@ -743,6 +919,7 @@ def run_planesweep(args, steps, warmup, with_cpu, cpu_reps=8):
            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": profiled_traffic(kname, f"{n_views}x{W}x{H}"),
+                        "traffic_source": profiled_traffic_and_source(kname, f"{n_views}x{W}x{H}")[1],
                         "algorithmic_bytes_per_launch": int(bytes_per_hyp * n_hyp),
                         "avg_launch_ms": round(launch_ms, 4), "launches_timed": steps}}
     # the HBM ruler does not describe this kernel (traffic << algorithmic bytes): its VALU-issue roofline

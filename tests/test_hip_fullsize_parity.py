@@ -122,6 +122,43 @@ def test_config5_4k_view_bit_exact(mode):
     _eq(normal[0], on, f"{mode} 4K normal")
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_config5_4k_full_schedule_on_the_whole_batch_policy(mode):
+    """Round 4: the late-iteration regime at 3840x2160.  Images wider than 2048 columns select
+    another launch policy than 1080p -- the whole 16-view batch per launch (default_views_per_launch), strips of the
+    reduced height pick_tile_rows chooses beyond 3072 columns -- and that policy had only met a 1 x (2 + 1) schedule.
+    Here: 16 views of 4K, the full 8 x (2 + 8) schedule, one view of the batch against the oracle (~12 s)."""
+    import amvs
+    from amvs.engine import make_pm_params
+    H, W, n = 2160, 3840, 16
+    sc = _u8_scene(n, H, W, 1234)
+    ids = sorted(sc.poses)
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    sources = [pm._select_source_views(r, ids, sc.poses, k=4) for r in ids]
+    import torch
+    dev = torch.device("cuda", 0)
+    hw = H * W
+    d = torch.empty((n, hw), dtype=torch.float32, device=dev)
+    nr = torch.empty((n, 3 * hw), dtype=torch.float32, device=dev)
+    cf = torch.empty((n, hw), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with amvs.Engine(H, W, n, sc.camera.K.astype(np.float32), mode=mode) as eng:
+        for i in ids:
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "u8-pairs"
+        eng.patchmatch_device(ids, sources, make_pm_params(7, 8, 8, sc.depth_min, sc.depth_max), 42,
+                              d.data_ptr(), nr.data_ptr(), cf.data_ptr())
+        eng.sync()
+        assert eng.last_views_per_launch() == 16 and eng.timing()["sweep_launches"] == 80
+    r = 9
+    od, on, oc = _oracle_ctx(sc, r, sources[r], 7, mode).patchmatch(8, 8, sc.depth_min, sc.depth_max, 42, r)
+    _eq(d[r].cpu().numpy().reshape(H, W), od, f"{mode} 4K full schedule view {r} depth")
+    _eq(cf[r].cpu().numpy().reshape(H, W), oc, f"{mode} 4K full schedule view {r} confidence")
+    _eq(nr[r].cpu().numpy().reshape(H, W, 3), on, f"{mode} 4K full schedule view {r} normal")
+    assert bool(torch.isfinite(d).all())
+
+
 @pytest.mark.parametrize("mode", ["fast", "exact"])
 def test_config2_8x720p_plane_sweep_bit_exact(mode):
     import torch

@@ -45,7 +45,7 @@ def _digest(t):
     return hashlib.sha1(t.contiguous().cpu().numpy().tobytes()).hexdigest()
 
 
-def _config4_sweep(views_per_batch, keep_rows=()):
+def _config4_sweep(views_per_batch, keep_rows=(), mode="fast"):
     """The config-4 scene through PatchMatchMVS._sweep_resident (sharded + gathered when a process
     group is initialised).  Returns ({view: (sha1 depth, sha1 normal, sha1 confidence)}, {view: maps
     of the rows asked for}, the prepared scene)."""
@@ -61,7 +61,7 @@ def _config4_sweep(views_per_batch, keep_rows=()):
     ids = sorted(sc.poses)
     pm = PatchMatchMVS(amvs.Camera(K=sc.camera.K.copy(), dist=np.zeros(5)), scale=1.0, patch_size=7,
                        num_iterations=c["iters"], num_samples=c["samples"], min_views=3, seed=c["seed"],
-                       views_per_batch=views_per_batch, device=0, mode="fast", device_prep=False)
+                       views_per_batch=views_per_batch, device=0, mode=mode, device_prep=False)
     pm.depth_min, pm.depth_max = sc.depth_min, sc.depth_max
     proc = {i: {"gray": sc.grays[i], "color": sc.colors[i], "shape": (c["H"], c["W"])} for i in ids}
     jobs = [(r, pm._select_source_views(r, ids, sc.poses, k=4)) for r in ids]
@@ -77,39 +77,41 @@ def _config4_sweep(views_per_batch, keep_rows=()):
     return digests, kept, (sc, jobs)
 
 
-def _config4_worker(rank, world, port, q, views_per_batch):
+def _config4_worker(rank, world, port, q, views_per_batch, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        digests, _, _ = _config4_sweep(views_per_batch)
+        digests, _, _ = _config4_sweep(views_per_batch, mode=mode)
         q.put((rank, digests))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.fixture(scope="module")
-def config4_single():
-    return _config4_sweep(16, keep_rows=(5, 26))
+@pytest.fixture(scope="module", params=["fast", "exact"])
+def config4_single(request):
+    """(digests, kept maps, scene, arithmetic mode) of the single-process sweep -- in the fast arithmetic the bench
+    times and in the exact one the classes default to (round 4)."""
+    return _config4_sweep(16, keep_rows=(5, 26), mode=request.param) + (request.param,)
 
 
 @pytest.mark.timeout(900)
 def test_config4_single_process_views_match_the_oracle(config4_single):
     from oracle import oracle
     oracle.set_threads(16)
-    _, kept, (sc, jobs) = config4_single
+    _, kept, (sc, jobs), mode = config4_single
     c = C4
     for r, (d, n, cf) in kept.items():
         srcs = jobs[r][1]
         ctx = oracle.ViewContext(sc.camera.K.astype(np.float32), sc.grays[r], sc.poses[r].R, sc.poses[r].t,
                                  [sc.grays[i] for i in srcs], [sc.poses[i].R for i in srcs],
-                                 [sc.poses[i].t for i in srcs], 7, mode="fast")
+                                 [sc.poses[i].t for i in srcs], 7, mode=mode)
         od, on, oc = ctx.patchmatch(c["iters"], c["samples"], sc.depth_min, sc.depth_max, c["seed"], r)
-        _eq(d, od, f"config 4 view {r} depth")
-        _eq(cf, oc, f"config 4 view {r} confidence")
-        _eq(n, on, f"config 4 view {r} normal")
+        _eq(d, od, f"config 4 ({mode}) view {r} depth")
+        _eq(cf, oc, f"config 4 ({mode}) view {r} confidence")
+        _eq(n, on, f"config 4 ({mode}) view {r} normal")
 
 
 @pytest.mark.timeout(900)
@@ -118,11 +120,13 @@ def test_config4_two_ranks_rank_shaped_shards_gathered(config4_single, views_per
     """Two gloo ranks on cuda:0, 16 views each, swept in launches of 8 (the 4-GPU shard) or 4 views (the
     8-GPU shard) and all-gathered: every rank ends with the single-process maps of all 32 views."""
     import torch.multiprocessing as mp
-    single, _, _ = config4_single
+    single, _, _, mode = config4_single
+    if mode == "exact" and views_per_batch != 8:
+        pytest.skip("the exact arithmetic runs the 4-GPU-shaped shard only (time)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_config4_worker, args=(r, 2, port, q, views_per_batch)) for r in range(2)]
+    procs = [ctx.Process(target=_config4_worker, args=(r, 2, port, q, views_per_batch, mode)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]
@@ -132,7 +136,7 @@ def test_config4_two_ranks_rank_shaped_shards_gathered(config4_single, views_per
     for rank, digests in results:
         assert sorted(digests) == sorted(single)
         bad = [r for r in single if digests[r] != single[r]]
-        assert not bad, f"rank {rank}, {views_per_batch} views per launch: gathered maps of views {bad} differ"
+        assert not bad, f"rank {rank}, {views_per_batch} views per launch ({mode}): gathered maps of views {bad} differ"
 
 
 @pytest.mark.timeout(1200)
@@ -295,6 +299,48 @@ def test_sweep_continued_one_iteration_per_call(scene_a, mode, entry):
             run(eng, n=1, first_iteration=1)                     # 3 iterations were run, not 1
         with pytest.raises(amvs.AmvsError):
             eng.patchmatch([2], [[1, 3, 0, 4]], make_pm_params(7, 1, samples, sc.depth_min, sc.depth_max, first_iteration=3), 9)
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_cli_default_reconstruct_equals_an_oracle_backed_run(mode, capsys):
+    """What run_reconstruction.py constructs (run_reconstruction.py:131-136, mvs_patchmatch.py:43-50):
+    PatchMatchMVS(camera, scale=0.25, num_iterations=3, min_views=3) -- patch 11, 3 x (2 + 8), depth range from the
+    camera spread (no sparse points) -- through reconstruct() end to end on 8-bit BGR inputs: device image
+    preparation, sweep, device fusion + filter.  The same run with every device step replaced: the host restatement
+    of the image preparation, the CPU oracle for every view's sweep, the NumPy fusion / filter of
+    core/mvs_patchmatch.py.  The two clouds must be identical, point for point."""
+    import torch
+
+    import amvs
+    from amvs.core.imageprep import prepare_views
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    oracle.set_threads(16)
+    n, h, w = 6, 432, 576                                   # processed at 108 x 144
+    sc = make_scene(n, h, w, seed=77, device="cuda" if torch.cuda.is_available() else "cpu")
+    cam = amvs.Camera(K=sc.camera.K.copy(), dist=np.zeros(5))
+    pm = amvs.PatchMatchMVS(cam, scale=0.25, num_iterations=3, min_views=3, seed=5, mode=mode)
+    assert (pm.patch_size, pm.num_samples) == (11, 8)
+    pts, cols = pm.reconstruct(sc.images(), sc.poses)
+    capsys.readouterr()
+    # ---- the same pipeline without the device ----
+    ids = sorted(sc.poses)
+    prepared = prepare_views([sc.colors[i] for i in ids], 0.25)
+    proc = dict(zip(ids, prepared))
+    K32 = pm.K_scaled.astype(np.float32)
+    maps = {}
+    for slot, r in enumerate(ids):
+        srcs = pm._select_source_views(r, ids, sc.poses, k=4)
+        ctx = oracle.ViewContext(K32, proc[r]["gray"], sc.poses[r].R, sc.poses[r].t, [proc[i]["gray"] for i in srcs],
+                                 [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], 11, mode=mode)
+        d, nr, cf = ctx.patchmatch(3, 8, pm.depth_min, pm.depth_max, 5, slot)
+        maps[r] = amvs.DepthNormalMap(depth=d, normal=nr, confidence=cf)
+        ctx.close()
+    want_p, want_c = pm._fuse_depth_maps(maps, proc, sc.poses)
+    assert len(want_p) > 0, "the scene must fuse some points for the comparison to mean anything"
+    want_p, want_c = pm._filter_points(want_p, want_c)
+    assert pts.shape == want_p.shape and np.array_equal(pts, want_p), f"{mode}: clouds differ ({len(pts)} vs {len(want_p)} points)"
+    assert np.array_equal(cols, want_c)
 
 
 def test_state_invalidation_flags_and_stale_step_times(scene_a):
