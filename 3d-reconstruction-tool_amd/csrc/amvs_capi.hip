@@ -2001,6 +2001,45 @@ int amvs_comm_destroy(amvs_ctx *c)
     return AMVS_OK;
 }
 
+// "%.6f" of a double, the bytes printf writes (correctly rounded decimal expansion of the exact binary value,
+// ties to even -- glibc), without printf for the common case: for |x| < 1e9 the scaled value x * 1e6 splits
+// into an integer n (exact as a double: below 2^53) and a residual r = fma(|x|, 1e6, -n), which is exact up to
+// one rounding far below the decision margin; the sixth decimal rounds up iff r > 1/2.  A residual within 1e-9
+// of 1/2 (true ties exist: 0.0078125 * 1e6 = 7812.5) and everything outside the range goes through snprintf.
+// (The per-point printf was 40 % of the CLI-default run's end-to-end time: 24 of 61 ms for 56 k points.)
+static inline char *put_u64(char *o, uint64_t v)
+{
+    char tmp[24];
+    int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) *o++ = tmp[--k];
+    return o;
+}
+
+static inline char *put_f6(char *o, double x)
+{
+    const double ax = std::fabs(x);
+    if (!(ax < 1e9)) return o + std::snprintf(o, 400, "%.6f", x);       // (also NaN / inf)
+    uint64_t n = (uint64_t)(ax * 1e6);
+    double r = std::fma(ax, 1e6, -(double)n);
+    if (r < 0.0) { n -= 1; r += 1.0; }
+    if (r >= 1.0) { n += 1; r -= 1.0; }
+    if (std::fabs(r - 0.5) < 1e-9 || r < 0.0 || r >= 1.0) return o + std::snprintf(o, 400, "%.6f", x);
+    if (r > 0.5) n += 1;
+    if (std::signbit(x)) *o++ = '-';
+    o = put_u64(o, n / 1000000u);
+    *o++ = '.';
+    uint32_t f = (uint32_t)(n % 1000000u);
+    for (int i = 5; i >= 0; --i) { o[i] = (char)('0' + f % 10); f /= 10; }
+    return o + 6;
+}
+
+static inline char *put_i64(char *o, long long v)
+{
+    if (v < 0) { *o++ = '-'; return put_u64(o, (uint64_t)(-(v + 1)) + 1u); }
+    return put_u64(o, (uint64_t)v);
+}
+
 int amvs_write_ply(const char *path, const double *points, const int64_t *colors, int64_t n)
 {
     if (!path || n < 0 || (n > 0 && (!points || !colors))) return fail(nullptr, AMVS_EINVAL, "bad argument");
@@ -2014,13 +2053,18 @@ int amvs_write_ply(const char *path, const double *points, const int64_t *colors
                                         (long long)n);
     bool ok = true;
     for (int64_t i = 0; i < n && ok; ++i) {
-        if (used + 256 > buf.size()) {
+        if (used + 1400 > buf.size()) {              // (a "%.6f" of the largest double is 316 characters)
             ok = std::fwrite(buf.data(), 1, used, f) == used;
             used = 0;
         }
-        used += (size_t)std::snprintf(buf.data() + used, 256, "%.6f %.6f %.6f %lld %lld %lld\n", points[3 * i],
-                                      points[3 * i + 1], points[3 * i + 2], (long long)colors[3 * i],
-                                      (long long)colors[3 * i + 1], (long long)colors[3 * i + 2]);
+        char *o = buf.data() + used;
+        o = put_f6(o, points[3 * i]); *o++ = ' ';
+        o = put_f6(o, points[3 * i + 1]); *o++ = ' ';
+        o = put_f6(o, points[3 * i + 2]); *o++ = ' ';
+        o = put_i64(o, (long long)colors[3 * i]); *o++ = ' ';
+        o = put_i64(o, (long long)colors[3 * i + 1]); *o++ = ' ';
+        o = put_i64(o, (long long)colors[3 * i + 2]); *o++ = '\n';
+        used = (size_t)(o - buf.data());
     }
     if (ok && used) ok = std::fwrite(buf.data(), 1, used, f) == used;
     ok = (std::fclose(f) == 0) && ok;

@@ -5,7 +5,7 @@ every (rows, workgroups per CU) of a grid; per-launch device times (amvs_get_ste
 iteration and by kind (propagation / refinement).  Also checks that the maps do not depend on the
 shape.  Prints one table line per combination and the per-iteration optimum.
 
-    python tools/r3_step_shape.py [--rows 8,12,16,24,32,48,64] [--caps 3,4,5,6] [--views 16] [--mode fast]
+    python tools/step_shape.py [--rows 8,12,16,24,32,48,64] [--caps 3,4,5,6] [--views 16] [--mode fast]
 """
 import argparse
 import hashlib
