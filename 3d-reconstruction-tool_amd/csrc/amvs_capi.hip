@@ -95,6 +95,7 @@ struct amvs_ctx {
     int mode = AMVS_MODE_EXACT;         // arithmetic of the sweeps (amvs_set_mode)
     int default_band_major = 0;         // schedule of amvs_pm_params.schedule == 0 (view-major measured faster)
     int sweep_tile_rows = 0, sweep_chunk = 0;   // amvs_set_sweep_tuning (0 = automatic)
+    int sweep_key8 = 1;                         // strips above 32 rows with 8-bit keys where the plane chunks allow it
     std::map<int, Stats> stats;
     std::map<int, FastStats> fstats;    // fast mode: (mean1, var1) maps per patch size
     int cap_slots = 0;
@@ -1197,7 +1198,7 @@ int amvs_set_sampling(amvs_ctx *c, int force_f32)
 int amvs_set_sweep_tuning(amvs_ctx *c, int tile_rows, int chunk)
 {
     if (!c) return AMVS_EINVAL;
-    if (tile_rows < 0 || tile_rows > AMVS_SWEEP_MAX_TH || chunk < 0)
+    if (tile_rows < 0 || tile_rows > AMVS_SWEEP_MAX_TH8 || chunk < 0)
         return fail(c, AMVS_EINVAL, "plane-sweep tuning out of range");
     c->sweep_tile_rows = tile_rows; c->sweep_chunk = chunk;
     return AMVS_OK;
@@ -1292,28 +1293,36 @@ int amvs_plane_sweep_device(amvs_ctx *c, int n_ref, const int *ref_ids, const in
     amvs::SweepArgs a{};
     a.H = c->H; a.W = c->W;
     // tall strips (little halo re-sampling); the planes are chunked so that the launch still has
-    // about four strips per resident wave slot
-    // (the fewest bands of at most AMVS_SWEEP_MAX_TH rows, evenly high: 720 rows -> 12 bands of 60)
-    {
-        const int bands = (c->H + AMVS_SWEEP_MAX_TH - 1) / AMVS_SWEEP_MAX_TH;
-        a.TH = (c->H + bands - 1) / bands;
-    }
-    if (c->sweep_tile_rows >= 1 && c->sweep_tile_rows <= AMVS_SWEEP_MAX_TH && c->sweep_tile_rows < c->H)
-        a.TH = c->sweep_tile_rows;
+    // about four strips per resident wave slot.  A strip's running best lives in 4 KB of LDS: 16-bit keys for up
+    // to AMVS_SWEEP_MAX_TH = 32 rows, or -- compiled patch sizes, chunks of at most 32 planes -- 8-bit keys for up
+    // to 64 rows (SweepArgs::key8); the fewest bands of at most that many rows, evenly high.
     a.tiles_x = (c->W + amvs::strip_out_width(patch_size) - 1) / amvs::strip_out_width(patch_size);
-    a.tiles_y = (c->H + a.TH - 1) / a.TH;
     a.n_jobs = n_ref; a.D = D;
-    {
+    auto shape = [&](int max_rows) {
+        const int bands = (c->H + max_rows - 1) / max_rows;
+        a.TH = (c->H + bands - 1) / bands;
+        if (c->sweep_tile_rows >= 1 && c->sweep_tile_rows <= max_rows && c->sweep_tile_rows < c->H) a.TH = c->sweep_tile_rows;
+        a.tiles_y = (c->H + a.TH - 1) / a.TH;
         const long long strips = (long long)n_ref * a.tiles_x * a.tiles_y;
         const long long slots = (long long)c->n_cu * 16;        // four waves per SIMD
-        long long want = (4 * slots + strips - 1) / strips;      // chunks for ~4 waves per slot
+        // chunks for ~8 waves per slot, evenly sized (measured on MI355X, config 2, strips of 60 rows, planes per
+        // wave 2 / 3 / 4 / 5 / 6 / 8 / 13: exact 51.7 / 50.0 / 51.7 / 50.7 / 49.8 / 49.2 / 46.1, fast 73.7 / 73.8 / 76.8 /
+        // 74.5 / 74.0 / 72.5 / 67.8 G px-hyp/s: many short waves fill the tail of the launch, uneven last chunks lose)
+        long long want = (8 * slots + strips - 1) / strips;
         if (want < 1) want = 1;
-        if (want > D) want = D;
+        if (want > (D + 1) / 2) want = (D + 1) / 2;              // (at least two planes per wave: a wave's set-up)
         a.chunk = (int)((D + want - 1) / want);
+        a.chunk = (int)((D + (D + a.chunk - 1) / a.chunk - 1) / ((D + a.chunk - 1) / a.chunk));   // even chunks
         if (c->sweep_chunk >= 1) a.chunk = c->sweep_chunk < D ? c->sweep_chunk : D;
         if (a.chunk > AMVS_SWEEP_MAX_CHUNK) a.chunk = AMVS_SWEEP_MAX_CHUNK;
         a.n_chunks = (D + a.chunk - 1) / a.chunk;
+    };
+    a.key8 = 0;
+    if (amvs::patch_compiled(patch_size) && c->sweep_key8 != 0 && (c->sweep_tile_rows == 0 || c->sweep_tile_rows > AMVS_SWEEP_MAX_TH)) {
+        shape(AMVS_SWEEP_MAX_TH8);
+        a.key8 = a.chunk <= AMVS_SWEEP_MAX_CHUNK8 ? 1 : 0;
     }
+    if (!a.key8) shape(AMVS_SWEEP_MAX_TH);
     c->last_tile_rows = a.TH;
     a.img_stride = c->stride;
     a.images = c->d_images;

@@ -4,8 +4,10 @@
 #include <stdint.h>
 
 #define AMVS_KMAX_SRC 6
-#define AMVS_SWEEP_MAX_TH 32
-#define AMVS_SWEEP_MAX_CHUNK 4096     // planes one wave sweeps (12-bit plane index in its LDS keys)
+#define AMVS_SWEEP_MAX_TH 32          // rows per strip with 16-bit running-best keys ...
+#define AMVS_SWEEP_MAX_CHUNK 4096     // ... of up to 4096 planes per wave (12-bit plane index in its LDS keys)
+#define AMVS_SWEEP_MAX_TH8 64         // rows per strip with 8-bit keys (SweepArgs::key8: the same 4 KB of LDS) ...
+#define AMVS_SWEEP_MAX_CHUNK8 32      // ... of up to 32 planes per wave (5-bit plane index, 3-bit vote count)
 #define AMVS_MAX_PATCH 31             // largest (odd) patch size: the run-time-k kernels' rings fit 64 KB of LDS up to here
 
 namespace amvs {
@@ -104,6 +106,7 @@ struct StepArgs : StepArgsBase {
 struct SweepArgs : StepArgsBase {
     int H, W, TH, tiles_x, tiles_y, n_jobs, D;
     int n_chunks, chunk;                     // planes are split into n_chunks groups of `chunk`
+    int key8;                                // 1: 8-bit running-best keys (chunk <= 32): strips of up to 64 rows in the same LDS
     unsigned *keys;                          // [slot][H*W] running best, merged with atomicMax
     const float *depths;                     // [D] device
     float thresh;

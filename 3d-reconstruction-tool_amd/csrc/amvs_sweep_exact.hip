@@ -155,7 +155,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
         rc.c0 = px * job->Kinv[0]; rc.c1 = px * job->Kinv[3]; rc.c2 = px * job->Kinv[6];
     }
 
-    for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
+    // running best per output pixel of the strip: 16-bit keys (votes << 12 | 4095 - plane of the chunk), or -- a.key8,
+    // chunks of at most 32 planes -- 8-bit keys (votes << 5 | 31 - plane) in the same array, for strips twice as high
+    uint8_t *best8 = (uint8_t *)&best[0][0];
+    if (a.key8) { for (int i = 0; i < trows; ++i) best8[i * AMVS_WAVE + lane] = (uint8_t)0; }
+    else { for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0; }
 
     for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[AMVS_IDX(d, a.D)];
@@ -241,11 +245,17 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
                 if (__builtin_expect(!__all(vok), 0)) vote_stage(std::false_type{}, vok);
             }
             if (outl) {
-                const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
-                const uint32_t cur = best[yc - y0][lane];
                 // the chunk's first plane always enters (torch.max over a volume that starts at 0
-                // votes): its key (0 << 12) | 4095 beats the initial 0
-                if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
+                // votes): its key (0 << 12) | 4095 -- (0 << 5) | 31 -- beats the initial 0
+                if (a.key8) {
+                    const uint32_t keyv = (votes << 5) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK8 - 1 - (d - d_begin));
+                    const uint32_t cur = best8[(yc - y0) * AMVS_WAVE + lane];
+                    if (keyv > cur) best8[(yc - y0) * AMVS_WAVE + lane] = (uint8_t)keyv;
+                } else {
+                    const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
+                    const uint32_t cur = best[yc - y0][lane];
+                    if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
+                }
             }
         }
     }
@@ -254,9 +264,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     const int xc = xr + HALF;
     if (lane < OUTW && xc < W)
         for (int i = 0; i < trows; ++i) {
-            const uint32_t b = best[i][lane];
-            const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], ((b >> 12) << 16) | (65535u - plane));
+            const uint32_t b = a.key8 ? (uint32_t)best8[i * AMVS_WAVE + lane] : (uint32_t)best[i][lane];
+            const uint32_t votes = a.key8 ? b >> 5 : b >> 12;
+            const uint32_t plane = (uint32_t)d_begin + (a.key8 ? AMVS_SWEEP_MAX_CHUNK8 - 1 - (b & (AMVS_SWEEP_MAX_CHUNK8 - 1))
+                                                                 : AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
+            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], (votes << 16) | (65535u - plane));
         }
 }
 

@@ -54,7 +54,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const int trows = min(a.TH, H - y0);
     const int rows = trows + 2 * HALF;
 
-    for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0;
+    // running best per output pixel of the strip: 16-bit keys (votes << 12 | 4095 - plane of the chunk), or -- a.key8,
+    // chunks of at most 32 planes -- 8-bit keys (votes << 5 | 31 - plane) in the same array, for strips twice as high
+    uint8_t *best8 = (uint8_t *)&best[0][0];
+    if (a.key8) { for (int i = 0; i < trows; ++i) best8[i * AMVS_WAVE + lane] = (uint8_t)0; }
+    else { for (int i = 0; i < trows; ++i) best[i][lane] = (uint16_t)0; }
 
     // The lean reciprocal (v_rcp_f32 + one FMA) equals 1.0f / z wherever 2^-95 <= |z| < 2^96
     // (amvs_device.h).  For a plane, z = fma(depth, fma(M7, y, t2), b2) + 1e-8 is monotonic along a
@@ -152,9 +156,15 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
                 if (__builtin_expect(!__all(ok), 0)) vote_stage(std::false_type{}, ok);
             }
             if (outl) {
-                const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
-                const uint32_t cur = best[yc - y0][lane];
-                if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
+                if (a.key8) {
+                    const uint32_t keyv = (votes << 5) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK8 - 1 - (d - d_begin));
+                    const uint32_t cur = best8[(yc - y0) * AMVS_WAVE + lane];
+                    if (keyv > cur) best8[(yc - y0) * AMVS_WAVE + lane] = (uint8_t)keyv;
+                } else {
+                    const uint32_t keyv = (votes << 12) | (uint32_t)(AMVS_SWEEP_MAX_CHUNK - 1 - (d - d_begin));
+                    const uint32_t cur = best[yc - y0][lane];
+                    if (keyv > cur) best[yc - y0][lane] = (uint16_t)keyv;
+                }
             }
         }
     }
@@ -163,9 +173,11 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     const int xc = xr + HALF;
     if (lane < OUTW && xc < W)
         for (int i = 0; i < trows; ++i) {
-            const uint32_t b = best[i][lane];
-            const uint32_t plane = (uint32_t)d_begin + (AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
-            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], ((b >> 12) << 16) | (65535u - plane));
+            const uint32_t b = a.key8 ? (uint32_t)best8[i * AMVS_WAVE + lane] : (uint32_t)best[i][lane];
+            const uint32_t votes = a.key8 ? b >> 5 : b >> 12;
+            const uint32_t plane = (uint32_t)d_begin + (a.key8 ? AMVS_SWEEP_MAX_CHUNK8 - 1 - (b & (AMVS_SWEEP_MAX_CHUNK8 - 1))
+                                                                 : AMVS_SWEEP_MAX_CHUNK - 1 - (b & (AMVS_SWEEP_MAX_CHUNK - 1)));
+            atomicMax(&keys[AMVS_IDX((y0 + i) * W + xc, HW)], (votes << 16) | (65535u - plane));
         }
 }
 

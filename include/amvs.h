@@ -165,7 +165,8 @@ int amvs_set_sampling(amvs_ctx *ctx, int force_f32);
  * A new context is in AMVS_MODE_EXACT.                                                       */
 int amvs_set_mode(amvs_ctx *ctx, int mode);
 int amvs_get_mode(const amvs_ctx *ctx);
-/* Plane-sweep launch shape: rows per wave strip (1..32) and planes per wave; 0 = automatic.   */
+/* Plane-sweep launch shape: rows per wave strip (1..64; more than 32 only for the compiled patch sizes and at most
+ * 32 planes per wave -- the strip's running best then uses 8-bit keys) and planes per wave; 0 = automatic.   */
 int amvs_set_sweep_tuning(amvs_ctx *ctx, int tile_rows, int planes_per_wave);
 /* Launch shape of the PatchMatch sweep steps by iteration (performance only; the maps do not depend
  * on it -- tests/test_hip_fullsize_parity.py): tile_rows / wgs_per_cu are [n_iterations][2] tables,

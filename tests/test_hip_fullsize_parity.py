@@ -180,7 +180,16 @@ def test_config2_8x720p_plane_sweep_bit_exact(mode):
         torch.cuda.synchronize()
         eng.plane_sweep_device(ids, nbrs, depths, k, 0.8, dmap.data_ptr(), conf.data_ptr())   # 8 views, one launch
         eng.sync()
-        assert eng.last_tile_rows() == 32                            # the 32-row best[][] LDS path
+        assert eng.last_tile_rows() == 60            # 12 bands of 60 rows: 8-bit running-best keys (chunks of 8 planes)
+        # the 16-bit keys' shape as well (23 bands of 32 rows; what every launch ran before round 4)
+        dmap32 = torch.empty_like(dmap)
+        conf32 = torch.empty_like(conf)
+        eng.set_sweep_tuning(tile_rows=32)
+        torch.cuda.synchronize()
+        eng.plane_sweep_device(ids, nbrs, depths, k, 0.8, dmap32.data_ptr(), conf32.data_ptr())
+        eng.sync()
+        assert eng.last_tile_rows() == 32
+    assert torch.equal(dmap, dmap32) and torch.equal(conf, conf32)
     dmap, conf = dmap.cpu().numpy(), conf.cpu().numpy()
     for r in (0, 5):
         od, oc = _oracle_ctx(sc, r, nbrs[r], k, mode).plane_sweep(depths, 0.8)

@@ -86,7 +86,7 @@ def fuzz_sweep(args, rng, amvs, make_scene, oracle):
         with amvs.Engine(H, W, n, K, mode=mode) as eng:
             for i in refs:
                 eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
-            eng.set_sweep_tuning(int(rng.choice([0, 0, 5, 13, 32])), int(rng.choice([0, 0, 1, 3, 7])))
+            eng.set_sweep_tuning(int(rng.choice([0, 0, 5, 13, 32, 47, 64])), int(rng.choice([0, 0, 1, 3, 7, 32, 40])))
             for r in refs[:3]:
                 nb = [int(j) for j in rng.permutation([j for j in refs if j != r])[:S]]
                 dm, cf = eng.plane_sweep(r, nb, depths, k, thresh)

@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", default="32,30,24,20,16")
-    ap.add_argument("--chunks", default="0,8,11,13,16,22,32")
+    ap.add_argument("--rows", default="60,48,40,32,24")
+    ap.add_argument("--chunks", default="0,4,6,8,11,13,16")
     ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
     args = ap.parse_args()
     import torch
