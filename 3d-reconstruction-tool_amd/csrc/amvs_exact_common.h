@@ -155,7 +155,10 @@ AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], f
 // then row (K-1-i) of the window, and the column sums take them newest first -- the same top -> bottom
 // order of the same values.
 // REFSUMS = false (the plane sweep, whose reference statistics come from the precomputed maps): br / brr are
-// not formed.
+// not formed.  (The sweep STEP keeps forming them from its ring: loading the two maps instead -- 8 B per pixel and
+// launch of coalesced traffic for 2K - 1 adds / FMAs and 2(K - 1) cross-lane adds less per row -- was measured
+// slower there in round 4: 37.7 against 40.4-40.7 G px-hyp/s at 7x7, 30.6 against 32.3 at 11x11; the step is not
+// bound by its instruction count alone, the plane sweep is.)
 template <int K, int S, bool REV = false, bool REFSUMS = true>
 AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
                           const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
