@@ -87,6 +87,10 @@ struct amvs_ctx {
     uint16_t *d_pairs = nullptr;
     long long pstride = 0;              // ushorts between packed maps
     unsigned char *d_bgr = nullptr;      // [n_views][H*W*3] prepared colour images (amvs_set_view_bgr8), lazily allocated
+    unsigned char *d_prep_src = nullptr; // staging of one uploaded source image + the resize tables (amvs_set_view_bgr8):
+    size_t cap_prep_src = 0;             // kept across calls -- a hipMalloc / hipFree pair per view cost more than the copy
+    int *d_prep_tab = nullptr;
+    size_t cap_prep_tab = 0;
     std::vector<char> have_bgr;
     int *d_flag = nullptr;               // [n_views] 1 = the view did not quantise to 8 bits losslessly
     mutable std::vector<char> exact8;    // host copy of !d_flag, refreshed lazily (flags_dirty)
@@ -911,6 +915,8 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_bgr) (void)hipFree(c->d_bgr);
+    if (c->d_prep_src) (void)hipFree(c->d_prep_src);
+    if (c->d_prep_tab) (void)hipFree(c->d_prep_tab);
     for (auto &kv : c->stats) {
         if (kv.second.mean) (void)hipFree(kv.second.mean);
         if (kv.second.var) (void)hipFree(kv.second.var);
@@ -1005,15 +1011,23 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
     resize_axis_tables(c->H, src_h, yofs, ibeta, false);
     // the prepared colour image stays on the device (the fusion reads it there: amvs_fuse_filter_views)
     if (!c->d_bgr) HIPCHK(c, hipMalloc(&c->d_bgr, 3 * n_dst * (size_t)c->n_views));
-    unsigned char *d_src = nullptr, *d_scaled = c->d_bgr + 3 * n_dst * (size_t)view;
-    int *d_tab = nullptr;
+    unsigned char *d_scaled = c->d_bgr + 3 * n_dst * (size_t)view;
     const size_t tab_ints = (size_t)c->W + c->H, tab_shorts = 2 * ((size_t)c->W + c->H);
-    auto cleanup = [&]() {
-        if (d_src) (void)hipFree(d_src);
-        if (d_tab) (void)hipFree(d_tab);
-    };
-    hipError_t e = hipMalloc(&d_src, 3 * n_src);
-    if (e == hipSuccess) e = hipMalloc(&d_tab, 4 * tab_ints + 2 * tab_shorts);
+    hipError_t e = hipSuccess;
+    if (3 * n_src > c->cap_prep_src) {
+        if (c->d_prep_src) (void)hipFree(c->d_prep_src);
+        c->d_prep_src = nullptr; c->cap_prep_src = 0;
+        e = hipMalloc(&c->d_prep_src, 3 * n_src);
+        if (e == hipSuccess) c->cap_prep_src = 3 * n_src;
+    }
+    if (e == hipSuccess && 4 * tab_ints + 2 * tab_shorts > c->cap_prep_tab) {
+        if (c->d_prep_tab) (void)hipFree(c->d_prep_tab);
+        c->d_prep_tab = nullptr; c->cap_prep_tab = 0;
+        e = hipMalloc(&c->d_prep_tab, 4 * tab_ints + 2 * tab_shorts);
+        if (e == hipSuccess) c->cap_prep_tab = 4 * tab_ints + 2 * tab_shorts;
+    }
+    unsigned char *d_src = c->d_prep_src;
+    int *d_tab = c->d_prep_tab;
     int *d_xofs = d_tab, *d_yofs = d_tab ? d_tab + c->W : nullptr;
     short *d_ialpha = d_tab ? (short *)(d_tab + tab_ints) : nullptr, *d_ibeta = d_ialpha ? d_ialpha + 2 * c->W : nullptr;
     if (e == hipSuccess) e = hipMemcpyAsync(d_src, bgr_host, 3 * n_src, hipMemcpyHostToDevice, c->stream);
@@ -1031,7 +1045,6 @@ int amvs_set_view_bgr8(amvs_ctx *c, int view, const uint8_t *bgr_host, int src_h
         e = amvs::launch_pack_pairs(c->d_images + view * c->stride, c->H, c->W, c->d_pairs + view * c->pstride,
                                     c->d_flag + view, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    cleanup();
     if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("set_view_bgr8: ") + hipGetErrorString(e));
     c->flags_dirty = true;
     c->have_bgr[view] = 1;
