@@ -82,6 +82,7 @@ SIGNATURES = {
                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "amvs_cloud_knn_mean_distance": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "amvs_cloud_voxel_downsample": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), C.c_double, C.POINTER(C.c_int64)]),
+    "amvs_cloud_take": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64]),
     "amvs_knn_supported": (C.c_int, [C.c_int]),
     "amvs_xpm_init": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, C.c_int, C.POINTER(XpmParams), C.c_uint64,
                                 C.c_void_p, C.c_void_p, C.c_void_p]),

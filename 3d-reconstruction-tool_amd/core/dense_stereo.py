@@ -209,11 +209,21 @@ class DenseStereoReconstructor:
         """_filter_outliers (:439-473) + _voxel_down_sample (:475-492) on the resident cloud.  The
         neighbour statistic comes from the GPU; mean + std_ratio * std and the comparison stay in numpy
         (as in the reference), the selection and the voxel grid run on the GPU again.  Clouds the
-        reference would sub-sample at random (> 500k points, unseeded np.random.choice) and neighbour
-        counts the device search is not compiled for take the host path."""
+        reference sub-samples at random (> 500k points, unseeded np.random.choice) are sub-sampled with the
+        same draw on the device (amvs_cloud_take); neighbour counts the device search is not compiled for take
+        the host path."""
+        host_path = not self.device_filter or not eng.knn_supported(k) or k >= min(total, 500000) // 2
         if total < k + 1:
             keep = None
-        elif total > 500000 or not self.device_filter or not eng.knn_supported(k) or k >= total // 2:
+        elif total > 500000 and not host_path and not getattr(self, "_subsample_on_host", False):
+            # the reference sub-samples clouds above 500 000 points at random (unseeded np.random.choice, :449-451)
+            # and filters the sample: the same draw, the sample taken on the device (amvs_cloud_take), so that the
+            # cloud never travels to the host -- the same points as the host path returns for the same draw
+            chosen = np.random.choice(total, 500000, replace=False)
+            total = eng.cloud_take(chosen)
+            mean_d = eng.cloud_knn_mean_distance(total, k)
+            keep = mean_d < np.mean(mean_d) + std_ratio * np.std(mean_d)
+        elif total > 500000 or host_path:
             points, colors = eng.fetch_cloud(total)
             points, colors = self._filter_outliers(points, colors, k, std_ratio)
             print(f"  After outlier removal: {len(points):,}")

@@ -1538,6 +1538,27 @@ int amvs_cloud_voxel_downsample(amvs_ctx *c, const uint8_t *keep_mask, double vo
     return AMVS_OK;
 }
 
+int amvs_cloud_take(amvs_ctx *c, const int64_t *indices, int64_t m)
+{
+    if (!c) return AMVS_EINVAL;
+    if (m < 0 || (m > 0 && !indices)) return fail(c, AMVS_EINVAL, "bad argument");
+    if (c->cloud_n < 1 && m > 0) return fail(c, AMVS_EINVAL, "no resident cloud");
+    int rc = bind_device(c);
+    if (rc) return rc;
+    static_assert(sizeof(long long) == sizeof(int64_t), "index width");
+    double *p2 = nullptr;
+    unsigned char *r2 = nullptr;
+    if (m > 0) {
+        hipError_t e = amvs::cloud_take(c->d_cloud_pts, c->d_cloud_rgb, c->cloud_n, (const long long *)indices, m, &p2, &r2, c->stream);
+        if (e == hipErrorInvalidValue) return fail(c, AMVS_EINVAL, "cloud_take: index outside the resident cloud");
+        if (e != hipSuccess) return fail(c, AMVS_EHIP, std::string("cloud_take: ") + hipGetErrorString(e));
+    }
+    if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
+    if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    c->d_cloud_pts = p2; c->d_cloud_rgb = r2; c->cloud_n = m;
+    return AMVS_OK;
+}
+
 int amvs_knn_supported(int k) { return amvs::knn_supported(k) ? 1 : 0; }
 
 // ---- extended mode (csrc/amvs_extended.hip) ----

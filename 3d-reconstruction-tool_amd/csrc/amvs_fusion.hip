@@ -158,6 +158,19 @@ __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ 
     }
 }
 
+// out[i] = src[idx[i]] for points and colours: the rows `idx` of a cloud, in that order
+__global__ __launch_bounds__(256) void take_kernel(const double *__restrict__ pts, const unsigned char *__restrict__ rgb,
+                                                   const long long *__restrict__ idx, long long m, long long n_src,
+                                                   double *__restrict__ pts_out, unsigned char *__restrict__ rgb_out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long s = AMVS_IDX(idx[i], n_src);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pts_out[3 * i + j] = pts[3 * s + j]; rgb_out[3 * i + j] = rgb[3 * s + j]; }
+    }
+}
+
 inline dim3 grid_for(long long n) { long long b = (n + 255) / 256; return dim3((unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b))); }
 
 struct Scratch {
@@ -381,6 +394,30 @@ hipError_t stereo_backproject(const float *depth, const float *conf, const unsig
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(pts); (void)hipFree(rgb); return e; }
     *pts_out = pts; *rgb_out = rgb;
+    return hipSuccess;
+}
+
+// points[chosen], colors[chosen] of a device cloud (dense_stereo.py:449-455: the random sub-sample of clouds above
+// 500 000 points; the caller draws `chosen` with numpy as the reference does): rows idx_h[0 .. m) in that order
+hipError_t cloud_take(const double *pts, const unsigned char *rgb, long long n, const long long *idx_h, long long m,
+                      double **pts_out, unsigned char **rgb_out, hipStream_t st)
+{
+    *pts_out = nullptr; *rgb_out = nullptr;
+    if (m <= 0) return hipSuccess;
+    for (long long i = 0; i < m; ++i)
+        if (idx_h[i] < 0 || idx_h[i] >= n) return hipErrorInvalidValue;
+    Scratch idx;
+    FCHK(idx.need(sizeof(long long) * m));
+    FCHK(hipMemcpyAsync(idx.p, idx_h, sizeof(long long) * m, hipMemcpyHostToDevice, st));
+    double *pts2 = nullptr;
+    unsigned char *rgb2 = nullptr;
+    FCHK(hipMalloc(&pts2, sizeof(double) * 3 * m));
+    hipError_t e = hipMalloc(&rgb2, 3 * m);
+    if (e != hipSuccess) { (void)hipFree(pts2); return e; }
+    hipLaunchKernelGGL(take_kernel, grid_for(m), dim3(256), 0, st, pts, rgb, (const long long *)idx.p, m, n, pts2, rgb2);
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(pts2); (void)hipFree(rgb2); return e; }
+    *pts_out = pts2; *rgb_out = rgb2;
     return hipSuccess;
 }
 

@@ -220,6 +220,8 @@ hipError_t launch_prep_bgr8(const unsigned char *src, int sh, int sw, int dh, in
 hipError_t stereo_backproject(const float *depth, const float *conf, const unsigned char *bgr, int n_maps, int H, int W,
                               const double *Kinv_h, const double *poses_h, float min_confidence, double **pts_out,
                               unsigned char **rgb_out, long long *total, long long *per_map_h, hipStream_t st);
+hipError_t cloud_take(const double *pts, const unsigned char *rgb, long long n, const long long *idx_h, long long m,
+                      double **pts_out, unsigned char **rgb_out, hipStream_t st);
 hipError_t voxel_downsample(const double *pts, const unsigned char *rgb, long long m, const unsigned char *keep_h,
                             double voxel, double **pts_out, unsigned char **rgb_out, long long *m_out, hipStream_t st);
 

@@ -375,6 +375,12 @@ class Engine:
         self._chk(self._lib.amvs_cloud_voxel_downsample(self._h, mp, float(voxel_size), C.byref(cnt)))
         return int(cnt.value)
 
+    def cloud_take(self, indices):
+        """The resident cloud <- its rows `indices` in that order (points[chosen], dense_stereo.py:449-455)."""
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        self._chk(self._lib.amvs_cloud_take(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.size))
+        return int(idx.size)
+
     def knn_supported(self, k):
         return bool(self._lib.amvs_knn_supported(int(k)))
 

@@ -830,6 +830,32 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
            "input_bytes_uploaded": int(n_views * h * w * 3)}
     assert len(pts2) == len(pts)
     eng.close()
+    # the CLI's other dense path (run_reconstruction.py:150-154): DenseStereoReconstructor(camera, scale=0.25)
+    # .reconstruct(images, poses, max_pairs=30) -- 64 planes, 5x5, 6 neighbours, exact arithmetic, image preparation,
+    # plane sweep, back-projection, outlier filter and voxel grid on the device -- and save_ply; second call timed
+    sink = open(os.devnull, "w")
+    with contextlib.redirect_stdout(sink):
+        ds = amvs.DenseStereoReconstructor(cam, scale=scale)
+        st = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            spts, scols = ds.reconstruct(images, small.poses, max_pairs=30)
+            t1 = time.perf_counter()
+            amvs_utils.save_ply(spts, scols, ply)
+            st.append((t1 - t0, time.perf_counter() - t1))
+        stm = ds._engine.timing() if ds._engine is not None else None
+    sink.close()
+    rec["stereo"] = {"workload": f"run_reconstruction.py defaults: DenseStereoReconstructor(scale=0.25) -- 64 planes, 5x5, 6 neighbours, "
+                                 f"min_views 3 --, the same {n_views} views, exact arithmetic, reconstruct(max_pairs=30) + save_ply end to end",
+                     "end_to_end_s": round(sum(st[1]), 4), "first_call_s": round(sum(st[0]), 4),
+                     "reconstruct_s": round(st[1][0], 4), "save_ply_s": round(st[1][1], 4),
+                     "sweep_kernel_ms": round(stm["sweep_ms"], 3) if stm else None,
+                     "pixel_hypotheses": int(n_views * H * W * ds.num_depths),
+                     "sweep_mpx_hyp_per_s": round(n_views * H * W * ds.num_depths / max(stm["sweep_ms"], 1e-9) / 1e3, 1) if stm else None,
+                     "dense_points": {"final": int(len(spts)), "points_per_s": round(len(spts) / max(sum(st[1]), 1e-9), 1)}}
+    if ds._engine is not None:
+        ds._engine.close()
     try:
         os.remove(ply)
         os.rmdir(tmp)

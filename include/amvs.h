@@ -226,6 +226,11 @@ int amvs_cloud_knn_mean_distance(amvs_ctx *ctx, int k, double *mean_out);
  * optional keep mask (one byte per point: the outlier filter's selection, computed by the caller as
  * the reference does with numpy): first point of every voxel in key order.  The cloud is replaced.  */
 int amvs_cloud_voxel_downsample(amvs_ctx *ctx, const uint8_t *keep_mask, double voxel_size, int64_t *count);
+/* The reference's random sub-sample of clouds above 500 000 points, points[chosen] / colors[chosen]
+ * (dense_stereo.py:449-455), on the resident cloud: it is replaced by its rows indices[0 .. m) in that order.  The
+ * caller draws the indices (the reference uses the unseeded np.random.choice; the Python class does the same), so
+ * the cloud need not travel to the host for the outlier statistic and the voxel grid that follow.                */
+int amvs_cloud_take(amvs_ctx *ctx, const int64_t *indices_host, int64_t m);
 /* 1 if amvs_knn_mean_distance is compiled for this neighbour count.                                */
 int amvs_knn_supported(int k);
 

@@ -534,6 +534,42 @@ def test_stereo_reconstruct_device_filter_equals_sklearn_filter(amvs_mod):
     assert np.array_equal(p_dev, p_host) and np.array_equal(c_dev, c_host)
 
 
+def test_stereo_big_cloud_random_subsample_on_the_device(amvs_mod, monkeypatch, capsys):
+    """Round 4: clouds above 500 000 points, which the reference sub-samples with an unseeded np.random.choice before
+    its outlier filter (dense_stereo.py:449-451).  The class makes the same draw and takes the sample on the device
+    (amvs_cloud_take), so the 2 M-point cloud never travels to the host; for the SAME draw it must return exactly
+    the cloud of the host path (fetch, points[chosen], neighbour statistic, numpy selection, numpy voxel grid)."""
+    import torch
+    from amvs.synthetic import make_scene
+    sc = make_scene(12, 756, 1008, seed=8, device="cuda" if torch.cuda.is_available() else "cpu")
+    images = sc.images()
+    cam = amvs_mod.Camera(K=sc.camera.K.copy(), dist=np.zeros(5))
+    draws = []
+    real_choice = np.random.choice
+
+    def counting_choice(*a, **k):
+        draws.append(a[0])
+        return real_choice(*a, **k)
+    monkeypatch.setattr(np.random, "choice", counting_choice)
+    out = {}
+    for where in ("device", "host"):
+        ds = amvs_mod.DenseStereoReconstructor(cam, scale=1.0, num_depths=32, min_views=2)
+        ds._subsample_on_host = where == "host"
+        np.random.seed(1234)
+        out[where] = ds.reconstruct(images, sc.poses)
+        ds._engine.close()
+    capsys.readouterr()
+    assert len(draws) == 2 and draws[0] == draws[1] and draws[0] > 500000, draws
+    assert len(out["device"][0]) > 10000
+    assert np.array_equal(out["device"][0], out["host"][0]) and np.array_equal(out["device"][1], out["host"][1])
+    # the entry point refuses indices outside the resident cloud
+    from amvs._lib import AmvsError
+    sc2 = GoldenScene("scene_c")
+    with sc2.engine() as eng:
+        with pytest.raises(AmvsError):
+            eng.cloud_take([0, 1, 2])                      # no resident cloud
+
+
 @pytest.mark.parametrize("scale", [1.0, 0.5, 0.25, 0.3, 0.6])
 def test_device_image_preparation_equals_host_restatement(amvs_mod, scale):
     """amvs_set_view_bgr8 (upload the 8-bit BGR image, cv.resize + cvtColor arithmetic on the GPU) against

@@ -34,7 +34,7 @@ def main():
     for case in range(args.cases):
         n = int(rng.integers(3, 8))
         H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
-        k = int(rng.choice([3, 5, 7, 9, 11]))
+        k = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 19]))          # (13 and up: the run-time-k kernels)
         S = int(rng.integers(2, min(n - 1, 6) + 1))
         iters, samples = int(rng.integers(2, 4)), int(rng.integers(1, 4))
         mode = str(rng.choice(["fast", "exact"]))
@@ -48,7 +48,8 @@ def main():
         with amvs.Engine(H, W, n, K, mode=mode) as eng:
             for i in refs:
                 eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
-            p = make_pm_params(k, iters, samples, sc.depth_min, sc.depth_max, tile_rows=rows, views_per_launch=vpl)
+            p = make_pm_params(k, iters, samples, sc.depth_min, sc.depth_max, tile_rows=rows, views_per_launch=vpl,
+                               schedule=str(rng.choice(["auto", "auto", "paired", "view-major"])))
             seed = int(rng.integers(0, 2 ** 31))
             d, nrm, cf = eng.patchmatch(refs, srcs, p, seed)
         bad = 0
@@ -60,7 +61,7 @@ def main():
                 same = (a == b) | (np.isnan(a) & np.isnan(b))
                 bad += int((~same).sum())
             ctx.close()
-        print(f"case {case}: {n} views {W}x{H} k={k} S={S} {iters}x(2+{samples}) {mode} vpl={vpl} rows={rows}: "
+        print(f"case {case}: {n} views {W}x{H} k={k} S={S} {iters}x(2+{samples}) {mode} vpl={vpl} rows={rows} {p.schedule}: "
               f"{'ok' if bad == 0 else str(bad) + ' ELEMENTS DIFFER'}", flush=True)
         if bad:
             sys.exit(1)
