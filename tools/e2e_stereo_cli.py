@@ -48,6 +48,19 @@ for name in ("_prepare_images_device", "_sweep_and_backproject", "_filter_and_do
         return wrap
     setattr(ds.DenseStereoReconstructor, name, make())
 timed(np.random, "choice", "np.random.choice")
+from amvs import engine as _eng  # noqa: E402
+for name in ("cloud_take", "cloud_knn_mean_distance", "cloud_voxel_downsample", "fetch_cloud", "stereo_backproject_views",
+             "stereo_backproject", "plane_sweep_batch"):
+    fn = getattr(_eng.Engine, name)
+
+    def make2(fn=fn, name=name):
+        def wrap(self, *a, **k):
+            t = time.perf_counter()
+            r = fn(self, *a, **k)
+            marks["eng." + name] = marks.get("eng." + name, 0.0) + time.perf_counter() - t
+            return r
+        return wrap
+    setattr(_eng.Engine, name, make2())
 sink = open(os.devnull, "w")
 for rep in range(3):
     marks.clear()

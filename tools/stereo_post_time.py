@@ -1,37 +1,51 @@
 #!/usr/bin/env python3
-"""Timing split of the stereo path's device post-steps on a synthetic 8-view 720p scene (GPU box)."""
+"""Timing split of the stereo path's device post-steps (GPU box): back-projection of the resident sweep maps,
+the reference's random sub-sample above 500 000 points on the device (amvs_cloud_take), neighbour statistic,
+threshold, voxel grid, fetch.
+
+    python tools/stereo_post_time.py [n_views H W]          default: 16 756 1008 (the CLI-default shape: a 2 M-point cloud)
+"""
+import contextlib
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
-import amvs  # noqa: E402,F401
-from amvs.core import dense_stereo as ds  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import amvs  # noqa: E402
 from amvs.synthetic import make_scene  # noqa: E402
 
-sc = make_scene(8, 720, 1280, device="cuda")
-images = [{"image": np.ascontiguousarray(c[:, :, ::-1])} for c in sc.colors]
-rec = ds.DenseStereoReconstructor(sc.camera, scale=1.0)
-rec.reconstruct(images, dict(sc.poses))
-eng = rec._engine
-proc = rec._engine_images
-ids = sorted(proc)
-K_inv = np.linalg.inv(rec.K_scaled)
-for rep in range(3):
-    t = [time.time()]
-    counts, total = eng.stereo_backproject(np.stack([proc[i]["color"] for i in ids]), K_inv,
-                                           [(sc.poses[i].R, sc.poses[i].t) for i in ids], 2.5)
-    t.append(time.time())
-    mean_d = eng.cloud_knn_mean_distance(total, 20)
-    t.append(time.time())
-    keep = mean_d < np.mean(mean_d) + 2.0 * np.std(mean_d)
-    t.append(time.time())
+n, H, W = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (16, 756, 1008)
+sc = make_scene(n, H, W, seed=4321, device="cuda")
+ids = sorted(sc.poses)
+ds = amvs.DenseStereoReconstructor(sc.camera, scale=1.0)
+with contextlib.redirect_stdout(open(os.devnull, "w")):
+    ds.reconstruct(sc.images(), sc.poses)
+eng = ds._engine
+K_inv = np.linalg.inv(ds.K_scaled)
+poses = [(sc.poses[i].R, sc.poses[i].t) for i in ids]
+slots = [ds._slot[i] for i in ids]
+for rep in range(4):
+    t = [time.perf_counter()]
+    counts, total = eng.stereo_backproject_views(slots, K_inv, poses, ds.min_views - 0.5)
+    t.append(time.perf_counter())
+    m0 = total
+    if total > 500000:
+        chosen = np.random.choice(total, 500000, replace=False)
+        t.append(time.perf_counter())
+        m0 = eng.cloud_take(chosen)
+    else:
+        t.append(time.perf_counter())
+    t.append(time.perf_counter())
+    md = eng.cloud_knn_mean_distance(m0, 20)
+    t.append(time.perf_counter())
+    keep = md < md.mean() + 2 * md.std()
+    t.append(time.perf_counter())
     m = eng.cloud_voxel_downsample(0.02, keep)
-    t.append(time.time())
-    pts, cols = eng.fetch_cloud(m)
-    t.append(time.time())
-    host = eng.knn_mean_distance(eng.fetch_cloud(m)[0], 20)
-    t.append(time.time())
-    print(f"rep {rep}: {total} pts: backproject {t[1]-t[0]:.4f}, knn(resident) {t[2]-t[1]:.4f}, threshold {t[3]-t[2]:.4f}, "
-          f"voxel {t[4]-t[3]:.4f} -> {m}, fetch {t[5]-t[4]:.4f}; knn(host cloud of {m}) {t[6]-t[5]:.4f}")
+    t.append(time.perf_counter())
+    p, c = eng.fetch_cloud(m)
+    t.append(time.perf_counter())
+    d = [1e3 * (b - a) for a, b in zip(t, t[1:])]
+    print(f"rep {rep}: {total} raw points: backproject {d[0]:.1f} ms, np.random.choice {d[1]:.1f}, take {d[2]:.1f}, knn({m0}) {d[3]:.1f}, "
+          f"threshold {d[4]:.1f}, voxel {d[5]:.1f} -> {m}, fetch {d[6]:.1f}", flush=True)
