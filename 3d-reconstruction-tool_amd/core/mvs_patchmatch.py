@@ -444,9 +444,7 @@ class PatchMatchMVS:
         # flattened scratch and copy out.  Job j = r * per + a + i (rank r, group [a, b), i < b - a) lives in
         # storage row world * a + r * (b - a) + i; rows of jobs >= n are padding.
         def store_row(j):
-            r, k = divmod(j, per)
-            a, b = next(g for g in groups if g[0] <= k < g[1])
-            return world * a + r * (b - a) + (k - a)
+            return self._storage_row(j, per, world, groups)
         depth = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
         normal = torch.zeros((world * per, 3 * hw), dtype=torch.float32, device=dev)
         conf = torch.zeros((world * per, hw), dtype=torch.float32, device=dev)
@@ -508,6 +506,15 @@ class PatchMatchMVS:
                   f"{int(valid[j]):,} valid pixels ({per_view:.1f}s)")
         return _ResidentMaps(ref_ids=[jobs[j][0] for j in range(n)], depth=depth, normal=normal,
                              confidence=conf, shape=(H, W))
+
+    @staticmethod
+    def _storage_row(j, per, world, groups):
+        """Storage row of job j in the several-rank _sweep_resident: rows are laid out [group][rank][row of the
+        group], so that the rows one group's exchange fills are ONE contiguous block (one all_gather_into_tensor
+        per map).  Job j = r * per + k belongs to rank r; k lies in group [a, b)."""
+        r, k = divmod(j, per)
+        a, b = next(g for g in groups if g[0] <= k < g[1])
+        return world * a + r * (b - a) + (k - a)
 
     def _exchange_streams(self, torch, dev):
         """The sweep / exchange streams of the several-rank path, created once per device and reused by every

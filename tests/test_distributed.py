@@ -345,6 +345,42 @@ def test_group_launch_plan_is_consistent_across_ranks():
                 assert all(s == seqs[0] for s in seqs), "ranks disagree about the collectives"
 
 
+def test_group_storage_layout_is_contiguous_per_exchange():
+    """PatchMatchMVS._storage_row (round 4): the several-rank _sweep_resident lays its maps out [group][rank][row], so
+    that (1) every job has its own row inside the world * per rows, (2) the rows of one group form ONE contiguous
+    block in which rank r's rows are the r-th equal slice -- the output and (in place) input of one
+    all_gather_into_tensor --, and (3) a launch, which never straddles a group, writes consecutive rows."""
+    import amvs
+    from amvs.parallel import shard
+    pm = amvs.PatchMatchMVS.__new__(amvs.PatchMatchMVS)
+    for n in (1, 2, 3, 5, 8, 16, 17, 32, 33, 64):
+        for world in (1, 2, 3, 4, 8):
+            per = -(-n // world)
+            jobs = [(j, [0, 1, 2, 3]) for j in range(n)]
+            groups_seen = None
+            rows = {}
+            for rank in range(world):
+                mine = shard(n, rank, world)
+                groups, plan = pm._plan_group_launches(jobs, mine, per, rank * per, 16)
+                assert groups_seen in (None, groups)
+                groups_seen = groups
+                for piece, _ in plan:
+                    if piece is None:
+                        continue
+                    r = [pm._storage_row(j, per, world, groups) for j in piece]
+                    assert r == list(range(r[0], r[0] + len(r))), "a launch must write consecutive rows"
+                    rows.update(zip(piece, r))
+            # every slot of the padded layout, not only the real jobs
+            all_rows = [pm._storage_row(j, per, world, groups_seen) for j in range(world * per)]
+            assert sorted(all_rows) == list(range(world * per)), (n, world)
+            assert all(rows[j] == all_rows[j] for j in rows)
+            for a, b in groups_seen:
+                g = b - a
+                for rank in range(world):
+                    got = [all_rows[rank * per + k] for k in range(a, b)]
+                    assert got == list(range(world * a + rank * g, world * a + (rank + 1) * g)), (n, world, a, b, rank)
+
+
 def test_bench_starts_its_own_ranks_and_reports_a_failing_one(tmp_path):
     """`python bench.py --gpus N` without a launcher starts N fresh child processes itself (bench.launch_ranks)
     before anything touches torch or the GPU, relays rank 0's stdout and fails when a rank fails -- and the

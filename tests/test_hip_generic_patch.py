@@ -202,6 +202,30 @@ def test_ragged_shapes_and_float_images_bit_exact(shape, k, S):
         _eq(normal[0], on, f"{shape} k{k} normal (8-bit {quantise})")
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_largest_patch_with_six_sources(scene_d, mode):
+    """k = 31 with S = 6: the largest LDS footprint of the run-time-k kernels (61.4 KB per wave for the sweep step,
+    63.3 KB for the plane sweep -- just under the 64 KB a workgroup may take): cost evaluation, a short sweep and the
+    plane sweep against the oracle."""
+    from amvs.engine import make_pm_params
+    ref, srcs, k = 3, [0, 1, 2, 4, 5, 6], 31
+    depth = _mixed_depth(scene_d, ref, 3)
+    depths = (1.0 / np.linspace(1 / scene_d.depth_max, 1 / scene_d.depth_min, 6)).astype(np.float32)
+    with scene_d.engine(mode) as eng:
+        cost = eng.eval_cost(ref, srcs, k, depth)
+        d, n, c = eng.patchmatch([ref], [srcs], make_pm_params(k, 1, 2, scene_d.depth_min, scene_d.depth_max), 4)
+        sd, sc_ = eng.plane_sweep(ref, srcs, depths, k, 0.5)
+    ctx = scene_d.oracle_ctx(ref, srcs, k, mode)
+    _eq(cost, ctx.patch_cost(depth), f"{mode} k31 S6 cost")
+    od, on, oc = ctx.patchmatch(1, 2, scene_d.depth_min, scene_d.depth_max, 4, ref)
+    _eq(d[0], od, f"{mode} k31 S6 depth")
+    _eq(n[0], on, f"{mode} k31 S6 normal")
+    _eq(c[0], oc, f"{mode} k31 S6 confidence")
+    osd, osc = ctx.plane_sweep(depths, 0.5)
+    _eq(sd, osd, f"{mode} k31 S6 sweep depth")
+    _eq(sc_, osc, f"{mode} k31 S6 sweep confidence")
+
+
 def test_classes_accept_any_odd_patch_size(scene_b, capsys):
     """PatchMatchMVS(patch_size=13) / DenseStereoReconstructor(patch_size=13) run end to end (the reference's
     constructors take any patch size); even and oversized patches are refused with a message."""
