@@ -66,6 +66,18 @@ def main():
         if bad:
             sys.exit(1)
     print("fuzz ok:", args.cases, "cases")
+    report_index_checks()
+
+
+def report_index_checks():
+    """With an index-checked library (AMVS_LIB=build/variants/libamvs_check.so) the random shapes also went through
+    the extent checks of every data-dependent global index: report, and fail on a violation."""
+    from amvs import _lib
+    if _lib.index_checks_enabled():
+        count, tu, line, index, extent = _lib.index_check()
+        print(f"index-checked build: {count} out-of-range accesses" + (f" (first: unit {tu} line {line}, index {index}, extent {extent})" if count else ""))
+        if count:
+            sys.exit(2)
 
 
 def fuzz_sweep(args, rng, amvs, make_scene, oracle):
@@ -101,6 +113,7 @@ def fuzz_sweep(args, rng, amvs, make_scene, oracle):
         if bad:
             sys.exit(1)
     print("sweep fuzz ok:", args.cases, "cases")
+    report_index_checks()
 
 
 if __name__ == "__main__":
