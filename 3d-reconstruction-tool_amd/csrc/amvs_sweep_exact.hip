@@ -319,6 +319,8 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
     case 7: AMVS_FOR_S(7, launch_sweep_ks, a, nblk, st)
     case 9: AMVS_FOR_S(9, launch_sweep_ks, a, nblk, st)
     case 11: AMVS_FOR_S(11, launch_sweep_ks, a, nblk, st)
+    case 13: AMVS_FOR_S(13, launch_sweep_ks, a, nblk, st)
+    case 15: AMVS_FOR_S(15, launch_sweep_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

@@ -1,7 +1,8 @@
-"""Any odd patch size (round 4): the run-time-k kernels of csrc/amvs_generic.hip against the CPU oracle, whose k is
-a run-time argument and which tests/test_oracle_modes_golden.py pins at k = 13, 15 against the reference's own
-outputs (g19, g20, g21).  The reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36,
-:325-341); the compiled kernels cover 3, 5, 7, 9, 11, every other odd size up to 31 runs here.
+"""Any odd patch size (round 4) against the CPU oracle, whose k is a run-time argument and which
+tests/test_oracle_modes_golden.py pins at k = 13, 15 against the reference's own outputs (g19, g20, g21).  The
+reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36, :325-341); the compiled kernels
+cover 3 ... 15 (13 and 15 since the end of round 4: 1.9x the run-time-k kernels' rate), every other odd size up to 31
+runs in the run-time-k kernels of csrc/amvs_generic.hip -- every test here visits both kinds.
 
 Bar: BIT-EXACT against the oracle in both arithmetic modes; the reference tolerances of tests/conftest.py against
 the goldens.
@@ -85,11 +86,12 @@ def test_confidence_bit_exact(eng_mode, scene_a):
         _eq(got, scene_a.oracle_ctx(ref, srcs, k, mode).confidence(g["depth"]), f"{mode} confidence k{k}")
 
 
+@pytest.mark.parametrize("k", [13, 17])
 @pytest.mark.parametrize("off", [(1, 0), (0, 1), (-1, 0), (0, -1)])
-def test_propagate_step_bit_exact(eng_mode, scene_a, off):
+def test_propagate_step_bit_exact(eng_mode, scene_a, off, k):
     eng, mode = eng_mode
     g = load_golden("g04_propagate")
-    ref, srcs, k = int(g["ref"]), list(g["srcs"]), 13
+    ref, srcs = int(g["ref"]), list(g["srcs"])
     # (g04's cost map belongs to another patch size: a first evaluation gives this patch's costs)
     cost = scene_a.oracle_ctx(ref, srcs, k, mode).patch_cost(g["depth"])
     got = eng.propagate_step(ref, srcs, k, g["depth"], g["normal"], cost, off[0], off[1], scene_a.depth_min)
@@ -100,12 +102,13 @@ def test_propagate_step_bit_exact(eng_mode, scene_a, off):
     assert (got[0] != g["depth"]).mean() > 0.01
 
 
+@pytest.mark.parametrize("k", [15, 19])
 @pytest.mark.parametrize("it", [0, 2])
-def test_refine_step_bit_exact(eng_mode, scene_a, it):
+def test_refine_step_bit_exact(eng_mode, scene_a, it, k):
     from oracle import oracle
     eng, mode = eng_mode
     g = load_golden("g05_refine")
-    ref, srcs, k, seed = int(g["ref"]), list(g["srcs"]), 15, int(g["seed"])
+    ref, srcs, seed = int(g["ref"]), list(g["srcs"]), int(g["seed"])
     dr = np.float32((scene_a.depth_max - scene_a.depth_min) * 0.5 ** it)
     nr = np.float32(0.5 * 0.5 ** it)
     ctx = scene_a.oracle_ctx(ref, srcs, k, mode)
@@ -173,7 +176,7 @@ def test_plane_sweep_k13_bit_exact_and_reference_golden(scene_d, mode):
     assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
 
 
-@pytest.mark.parametrize("shape,k,S", [((33, 59), 13, 3), ((70, 117), 15, 3), ((41, 200), 25, 2), ((20, 64), 31, 3)])
+@pytest.mark.parametrize("shape,k,S", [((33, 59), 13, 3), ((70, 117), 15, 3), ((35, 61), 17, 3), ((41, 200), 25, 2), ((20, 64), 31, 3)])
 def test_ragged_shapes_and_float_images_bit_exact(shape, k, S):
     """Widths that are not multiples of the strip's output width (64 - 2 (k/2)), heights below the patch size, and
     rendered float images (not 8-bit exact: the exact arithmetic samples the float32 maps, U8 = false)."""
@@ -226,19 +229,20 @@ def test_largest_patch_with_six_sources(scene_d, mode):
     _eq(sc_, osc, f"{mode} k31 S6 sweep confidence")
 
 
-def test_classes_accept_any_odd_patch_size(scene_b, capsys):
-    """PatchMatchMVS(patch_size=13) / DenseStereoReconstructor(patch_size=13) run end to end (the reference's
-    constructors take any patch size); even and oversized patches are refused with a message."""
+@pytest.mark.parametrize("patch", [13, 17])
+def test_classes_accept_any_odd_patch_size(scene_b, capsys, patch):
+    """PatchMatchMVS(patch_size=13 / 17) / DenseStereoReconstructor(patch_size=13 / 17) run end to end (the
+    reference's constructors take any patch size); even and oversized patches are refused with a message."""
     import amvs
     from amvs._lib import AmvsError
     cam = amvs.Camera(K=scene_b.K.copy(), dist=np.zeros(5))
     images = [{"image": c} for c in scene_b.colors]
-    pm = amvs.PatchMatchMVS(cam, scale=1.0, patch_size=13, num_iterations=2, num_samples=2, min_views=2,
+    pm = amvs.PatchMatchMVS(cam, scale=1.0, patch_size=patch, num_iterations=2, num_samples=2, min_views=2,
                             depth_min=scene_b.depth_min, depth_max=scene_b.depth_max, seed=3)
     pm._estimate_depth_range = lambda poses, pts=None: None           # keep the scene's own range
     pts, cols = pm.reconstruct(images, scene_b.poses())
     assert pts.ndim == 2 and pts.shape[1] == 3 and len(pts) == len(cols)
-    ds = amvs.DenseStereoReconstructor(cam, scale=1.0, num_depths=8, patch_size=13, min_views=2)
+    ds = amvs.DenseStereoReconstructor(cam, scale=1.0, num_depths=8, patch_size=patch, min_views=2)
     pts2, cols2 = ds.reconstruct(images, scene_b.poses())
     assert pts2.ndim == 2 and len(pts2) == len(cols2)
     capsys.readouterr()

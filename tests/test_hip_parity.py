@@ -264,6 +264,93 @@ def test_tiny_and_wide_source_sets_bit_exact(amvs_mod, shape, nviews, k, S):
             _eq(c, wc, "sweep confidence")
 
 
+@pytest.mark.parametrize("shape,k,S,thr", [((37, 83), 5, 4, 0.8), ((70, 150), 5, 6, 0.35), ((41, 66), 7, 3, 0.8),
+                                            ((33, 130), 3, 2, 0.05), ((52, 71), 9, 6, 0.93), ((29, 64), 11, 5, 0.8)])
+def test_plane_sweep_float_images_bit_exact(amvs_mod, shape, k, S, thr):
+    """The plane sweep on images that are NOT 8-bit exact (rendered floats: the float32 sampling path of the
+    compiled plane-sweep kernels), planes from well in front of the scene to far behind it, several thresholds
+    (the exact sweep's squared-comparison vote gate with its exact fall-back) -- and the same images once more
+    through the packed path's switch (force_f32 on an 8-bit scene) must not change a bit.  Exact arithmetic: the
+    fast mode samples the packed maps only and refuses other images (test_hip_fast_parity.py)."""
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    mode = "exact"
+    H, W = shape
+    n = S + 1
+    sc = make_scene(n, H, W, seed=H + W + k, arc_step_deg=14.0)
+    K = sc.camera.K.astype(np.float32)
+    ref = n // 2
+    srcs = [i for i in range(n) if i != ref]
+    planes = (1.0 / np.linspace(1 / (sc.depth_max * 3.0), 1 / (sc.depth_min * 0.3), 24)).astype(np.float32)
+    with amvs_mod.Engine(H, W, n, K, mode=mode) as eng:
+        for i in range(n):
+            eng.set_view(i, sc.grays[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "f32"
+        ctx = oracle.ViewContext(K, sc.grays[ref], sc.poses[ref].R, sc.poses[ref].t, [sc.grays[i] for i in srcs],
+                                 [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k, mode=mode)
+        for tile_rows in (0, 8):
+            eng.set_sweep_tuning(tile_rows, 0)
+            d, c = eng.plane_sweep(ref, srcs, planes, k, thr)
+            wd, wc = ctx.plane_sweep(planes, thr)
+            _eq(d, wd, f"{mode} k{k} S{S} rows {tile_rows} sweep depth")
+            _eq(c, wc, f"{mode} k{k} S{S} rows {tile_rows} sweep confidence")
+        assert c.max() > 0                                   # votes were cast: the comparison is not of empty maps
+    g8 = [np.round(g * 255.0).astype(np.uint8).astype(np.float32) / np.float32(255.0) for g in sc.grays]
+    with amvs_mod.Engine(H, W, n, K, mode=mode) as eng:
+        for i in range(n):
+            eng.set_view(i, g8[i], sc.poses[i].R, sc.poses[i].t)
+        assert eng.sampling_mode() == "u8-pairs"
+        packed = eng.plane_sweep(ref, srcs, planes, k, thr)
+        eng.set_sampling(force_f32=True)
+        plain = eng.plane_sweep(ref, srcs, planes, k, thr)
+        _eq(plain[0], packed[0], "forced float path: depth")
+        _eq(plain[1], packed[1], "forced float path: confidence")
+        ctx8 = oracle.ViewContext(K, g8[ref], sc.poses[ref].R, sc.poses[ref].t, [g8[i] for i in srcs],
+                                  [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k, mode=mode)
+        wd, wc = ctx8.plane_sweep(planes, thr)
+        _eq(packed[0], wd, "8-bit sweep depth")
+        _eq(packed[1], wc, "8-bit sweep confidence")
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("shape", [(2, 2), (2, 9), (9, 2), (3, 64), (64, 3), (2, 65), (5, 55), (4, 129)])
+def test_smallest_images_every_patch_size(amvs_mod, mode, shape):
+    """The smallest images the context accepts (2 x 2; the reference's grid normalisation divides by W - 1) up to
+    one-strip-plus-one-column widths, with every compiled patch size and two run-time ones -- patches larger than
+    the whole image, a single output row or column, strips whose halo is the entire strip: PatchMatch, plane sweep,
+    cost and confidence maps, bit for bit."""
+    from amvs.engine import make_pm_params
+    from amvs.synthetic import make_scene
+    from oracle import oracle
+    H, W = shape
+    sc = make_scene(4, max(H, 16), max(W, 16), seed=H * 131 + W)          # rendered larger, cropped: poses stay sane
+    grays = [(np.round(g[:H, :W] * 255.0).astype(np.uint8)).astype(np.float32) / np.float32(255.0) for g in sc.grays]
+    grays = [np.ascontiguousarray(g) for g in grays]
+    K = sc.camera.K.astype(np.float32)
+    srcs = [0, 2, 3]
+    planes = (1.0 / np.linspace(1 / sc.depth_max, 1 / sc.depth_min, 7)).astype(np.float32)
+    with amvs_mod.Engine(H, W, 4, K, mode=mode) as eng:
+        for i in range(4):
+            eng.set_view(i, grays[i], sc.poses[i].R, sc.poses[i].t)
+        for k in (3, 5, 7, 9, 11, 13, 31):
+            ctx = oracle.ViewContext(K, grays[1], sc.poses[1].R, sc.poses[1].t, [grays[i] for i in srcs],
+                                     [sc.poses[i].R for i in srcs], [sc.poses[i].t for i in srcs], k, mode=mode)
+            p = make_pm_params(k, 2, 2, sc.depth_min, sc.depth_max)
+            depth, normal, conf = eng.patchmatch([1], [srcs], p, 5)
+            od, on, oc = ctx.patchmatch(2, 2, sc.depth_min, sc.depth_max, 5, 1)
+            tag = f"{mode} {H}x{W} k{k}"
+            _eq(depth[0], od, tag + " depth")
+            _eq(conf[0], oc, tag + " confidence")
+            _eq(normal[0], on, tag + " normal")
+            d, c = eng.plane_sweep(1, srcs, planes, k, 0.5)
+            wd, wc = ctx.plane_sweep(planes, 0.5)
+            _eq(d, wd, tag + " sweep depth")
+            _eq(c, wc, tag + " sweep confidence")
+            flat = np.full((H, W), np.float32(0.5 * (sc.depth_min + sc.depth_max)), np.float32)
+            _eq(eng.eval_cost(1, srcs, k, flat), ctx.patch_cost(flat), tag + " cost")
+            _eq(eng.confidence(1, srcs, k, flat), ctx.confidence(flat), tag + " confidence of a flat map")
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_shapes_wide_baselines_bit_exact(amvs_mod, seed):
     """Random small shapes, patch sizes and source counts with wide baselines and a depth range that

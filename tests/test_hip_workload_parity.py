@@ -225,13 +225,15 @@ def test_strip_orders_give_identical_maps(mode):
 
 
 @pytest.mark.parametrize("mode", ["fast", "exact"])
-@pytest.mark.parametrize("k", [9, 11])
+@pytest.mark.parametrize("k", [9, 11, 13])
 def test_paired_bands_for_large_patches(mode, k):
     """Round 4: paired bands for 9x9 and 11x11 patches -- the partner band's rows of the LDS-resident sources are
     read from the partner's ring itself, the register-resident ones through exchange rows.  Even band counts with
     a short last band (300 = 18 x 16 + 12), an odd count (15 bands of 20), bands shorter than the halo (4 rows:
     the partner's "own rows next to the boundary" reach into its far halo), one band per view -- all equal to the
-    classic strips bit for bit, which the other parity tests pin to the oracle."""
+    classic strips bit for bit, which the other parity tests pin to the oracle.  (13 x 13: compiled, not paired --
+    a request for the paired schedule runs the classic strips; same maps, and the oracle comparison below covers the
+    compiled 13 x 13 kernels at several strip heights on a multi-strip image.)"""
     import torch
 
     import amvs
