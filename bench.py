@@ -748,14 +748,26 @@ def run_patchmatch_single(sc, sources, ids, H, W, mode, patch, iters, samples, s
     return rec
 
 
+# The end-to-end records time THREE calls after the first and report the median one (all three are listed): the second
+# call of a process -- what round 4 first reported -- is where glibc returns its first multi-megabyte array to the
+# system, and on this driver a host munmap within a few milliseconds of a GPU submission can hold that submission for
+# 20-30 ms (tools/README.md); later calls find the allocator's thresholds adapted.
+CLI_TIMED_CALLS = 3
+CLI_TIMED_NOTE = "median of 3 calls after the first (each listed in timed_calls_s)"
+
+
+def _median_call(calls):
+    return sorted(calls, key=lambda t: t[0] + t[1])[len(calls) // 2]
+
+
 def run_cli_defaults(n_views=16, h=3024, w=4032):
     """What the reference's CLI runs (run_reconstruction.py:131-136): PatchMatchMVS(camera, scale=0.25,
     num_iterations=3, min_views=3) -- patch 11, 3 x (2 + 8), 4 sources, the classes' default (exact) arithmetic --
     on 16 views of 4032x3024 (12 MP; processed at 1008x756), END TO END through PatchMatchMVS.reconstruct and
     utils.save_ply: 8-bit BGR uploads + image preparation on the device, depth range, source selection, sweep,
-    fusion + filter on the device, PLY file.  The timed call is the second one (the first pays the one-off
-    allocations and the first-use compilation of nothing -- there is no JIT -- but the page-in of the library);
-    the split is measured on a third pass through the class's own steps."""
+    fusion + filter on the device, PLY file.  Three calls are timed after the first (which pays the one-off
+    allocations and the page-in of the library -- there is no JIT); `end_to_end_s` is the median one
+    (CLI_TIMED_CALLS above); the split is measured on a further pass through the class's own steps."""
     import contextlib
     import tempfile
 
@@ -780,13 +792,14 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
         tmp = tempfile.mkdtemp(prefix="amvs_bench_")
         ply = os.path.join(tmp, "cloud.ply")
         timings = []
-        for _ in range(2):
+        for _ in range(1 + CLI_TIMED_CALLS):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             pts, cols = pm.reconstruct(images, small.poses)
             t1 = time.perf_counter()
             amvs_utils.save_ply(pts, cols, ply)
             timings.append((t1 - t0, time.perf_counter() - t1))
+        timings = [timings[0], _median_call(timings[1:])] + timings[1:]
         # the split, through the class's own steps
         t0 = time.perf_counter()
         pm._estimate_depth_range(small.poses, None)
@@ -813,6 +826,7 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
     rec = {"workload": f"run_reconstruction.py defaults: PatchMatchMVS(scale=0.25, patch 11, 3 iters x (2+8), min_views 3), "
                        f"{n_views} views of {w}x{h} processed at {W}x{H}, exact arithmetic, reconstruct() + save_ply end to end",
            "end_to_end_s": round(sum(timings[1]), 4), "first_call_s": round(sum(timings[0]), 4),
+           "timed_calls_s": [round(sum(t), 4) for t in timings[2:]], "timed": CLI_TIMED_NOTE,
            "reconstruct_s": round(timings[1][0], 4), "save_ply_s": round(timings[1][1], 4),
            "split_s": {"upload_and_image_preparation": round(t1 - t0, 4), "sweep": round(t2 - t1, 4),
                        "fusion_and_filter": round(t3 - t2, 4)},
@@ -832,23 +846,25 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
     eng.close()
     # the CLI's other dense path (run_reconstruction.py:150-154): DenseStereoReconstructor(camera, scale=0.25)
     # .reconstruct(images, poses, max_pairs=30) -- 64 planes, 5x5, 6 neighbours, exact arithmetic, image preparation,
-    # plane sweep, back-projection, outlier filter and voxel grid on the device -- and save_ply; second call timed
+    # plane sweep, back-projection, outlier filter and voxel grid on the device -- and save_ply; median of three calls after the first
     sink = open(os.devnull, "w")
     with contextlib.redirect_stdout(sink):
         ds = amvs.DenseStereoReconstructor(cam, scale=scale)
         st = []
-        for _ in range(2):
+        for _ in range(1 + CLI_TIMED_CALLS):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             spts, scols = ds.reconstruct(images, small.poses, max_pairs=30)
             t1 = time.perf_counter()
             amvs_utils.save_ply(spts, scols, ply)
             st.append((t1 - t0, time.perf_counter() - t1))
+        st = [st[0], _median_call(st[1:])] + st[1:]
         stm = ds._engine.timing() if ds._engine is not None else None
     sink.close()
     rec["stereo"] = {"workload": f"run_reconstruction.py defaults: DenseStereoReconstructor(scale=0.25) -- 64 planes, 5x5, 6 neighbours, "
                                  f"min_views 3 --, the same {n_views} views, exact arithmetic, reconstruct(max_pairs=30) + save_ply end to end",
                      "end_to_end_s": round(sum(st[1]), 4), "first_call_s": round(sum(st[0]), 4),
+                     "timed_calls_s": [round(sum(t), 4) for t in st[2:]],
                      "reconstruct_s": round(st[1][0], 4), "save_ply_s": round(st[1][1], 4),
                      "sweep_kernel_ms": round(stm["sweep_ms"], 3) if stm else None,
                      "pixel_hypotheses": int(n_views * H * W * ds.num_depths),
