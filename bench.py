@@ -748,12 +748,12 @@ def run_patchmatch_single(sc, sources, ids, H, W, mode, patch, iters, samples, s
     return rec
 
 
-# The end-to-end records time THREE calls after the first and report the median one (all three are listed): the second
-# call of a process -- what round 4 first reported -- is where glibc returns its first multi-megabyte array to the
-# system, and on this driver a host munmap within a few milliseconds of a GPU submission can hold that submission for
-# 20-30 ms (tools/README.md); later calls find the allocator's thresholds adapted.
-CLI_TIMED_CALLS = 3
-CLI_TIMED_NOTE = "median of 3 calls after the first (each listed in timed_calls_s)"
+# The end-to-end records time FIVE calls after the first and report the median one (all five are listed): on this
+# driver a host mmap / munmap of a multi-megabyte array (np.random.choice's permutation, any array glibc serves
+# from or returns to the system) within a few milliseconds of a GPU submission can hold that submission for 15-30 ms
+#  -- most often in the first calls of a process, before glibc's thresholds have adapted.
+CLI_TIMED_CALLS = 5
+CLI_TIMED_NOTE = "median of 5 calls after the first (each listed in timed_calls_s)"
 
 
 def _median_call(calls):
@@ -765,7 +765,7 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
     num_iterations=3, min_views=3) -- patch 11, 3 x (2 + 8), 4 sources, the classes' default (exact) arithmetic --
     on 16 views of 4032x3024 (12 MP; processed at 1008x756), END TO END through PatchMatchMVS.reconstruct and
     utils.save_ply: 8-bit BGR uploads + image preparation on the device, depth range, source selection, sweep,
-    fusion + filter on the device, PLY file.  Three calls are timed after the first (which pays the one-off
+    fusion + filter on the device, PLY file.  Five calls are timed after the first (which pays the one-off
     allocations and the page-in of the library -- there is no JIT); `end_to_end_s` is the median one
     (CLI_TIMED_CALLS above); the split is measured on a further pass through the class's own steps."""
     import contextlib
@@ -846,7 +846,7 @@ def run_cli_defaults(n_views=16, h=3024, w=4032):
     eng.close()
     # the CLI's other dense path (run_reconstruction.py:150-154): DenseStereoReconstructor(camera, scale=0.25)
     # .reconstruct(images, poses, max_pairs=30) -- 64 planes, 5x5, 6 neighbours, exact arithmetic, image preparation,
-    # plane sweep, back-projection, outlier filter and voxel grid on the device -- and save_ply; median of three calls after the first
+    # plane sweep, back-projection, outlier filter and voxel grid on the device -- and save_ply; median of five calls after the first
     sink = open(os.devnull, "w")
     with contextlib.redirect_stdout(sink):
         ds = amvs.DenseStereoReconstructor(cam, scale=scale)
