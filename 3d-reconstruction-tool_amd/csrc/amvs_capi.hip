@@ -6,6 +6,7 @@
 // together, one kernel launch per cost-evaluation step over the whole batch.
 #include "../../include/amvs.h"
 #include "amvs_kernels.h"
+#include "amvs_pool.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types only: the library is resolved at run time (amvs_comm_*)
@@ -911,6 +912,7 @@ int amvs_destroy(amvs_ctx *c)
     if (c->d_sweep_conf) (void)hipFree(c->d_sweep_conf);
     if (c->d_cloud_pts) (void)hipFree(c->d_cloud_pts);
     if (c->d_cloud_rgb) (void)hipFree(c->d_cloud_rgb);
+    amvs::pool_trim();                  // the post-steps' cached scratch blocks (amvs_pool.hip)
     if (c->d_images) (void)hipFree(c->d_images);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_flag) (void)hipFree(c->d_flag);

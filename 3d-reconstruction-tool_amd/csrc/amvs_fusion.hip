@@ -8,6 +8,7 @@
 #define AMVS_TU_ID 7
 #include "amvs_check.h"
 #include "amvs_kernels.h"
+#include "amvs_pool.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -179,13 +180,13 @@ struct Scratch {
     hipError_t need(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) pool_free(p);
         p = nullptr; cap = 0;
-        hipError_t e = hipMalloc(&p, n);
+        hipError_t e = pool_malloc(&p, n);                  // (amvs_pool.hip: blocks cached between calls)
         if (e == hipSuccess) cap = n;
         return e;
     }
-    ~Scratch() { if (p) (void)hipFree(p); }
+    ~Scratch() { if (p) pool_free(p); }
 };
 
 // order-preserving selection of the indices [0,n) whose flag is set

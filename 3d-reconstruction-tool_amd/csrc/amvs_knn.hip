@@ -19,10 +19,12 @@
 #define AMVS_TU_ID 8
 #include "amvs_check.h"
 #include "amvs_kernels.h"
+#include "amvs_pool.h"
 
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -112,6 +114,22 @@ __device__ __forceinline__ double numpy_pairwise_sum(const double (&a)[KNN_KMAX]
     return res;
 }
 
+// One more candidate for a list of the K smallest values kept in ASCENDING order: a chain of min / max pairs carries
+// the new value to its place and drops the largest -- 2 K double-precision instructions, no compares, no selects
+// (the first version replaced the current largest and searched the new one: 6-7 instructions per entry; the lists
+// are what the search kernels spend their time on: 6.4e8 VALU wave-instructions per 500 000 queries).
+template <int K>
+__device__ __forceinline__ void knn_insert(double (&best)[KNN_KMAX], double &worst, double x)
+{
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const double lo = fmin(best[j], x);
+        x = fmax(best[j], x);
+        best[j] = lo;
+    }
+    worst = best[K - 1];
+}
+
 // The cell walk: every query walks at most `max_shells` Chebyshev shells of cells around its own;
 // those that cover their k-th distance write their mean and clear the flag, the others stay pending
 // for knn_box_kernel.
@@ -130,32 +148,26 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
     const double qx = sorted[3 * q], qy = sorted[3 * q + 1], qz = sorted[3 * q + 2];
     const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
 
-    // the K smallest squared distances seen so far (unsorted) and the largest of them
+    // the K smallest squared distances seen so far, ascending, and the largest of them
     double best[KNN_KMAX];
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
     double worst = __builtin_inf();
 
-    auto visit_cell = [&](int x, int y, int z) {
-        const int c = AMVS_IDX((z * gr.g[1] + y) * gr.g[0] + x, (long long)gr.g[0] * gr.g[1] * gr.g[2]);
-        const int b = AMVS_IDX(start[c], n + 1), e = AMVS_IDX(start[c + 1], n + 1);
+    // the cells x_first .. x_last of grid row (y, z): consecutive in `start`, so their points are ONE range of the
+    // sorted array -- one pair of look-ups per row of a shell's face instead of one per cell (45 instead of 125 for
+    // shells 0..2: the walk is a chain of dependent loads, not arithmetic)
+    auto visit_row = [&](int x_first, int x_last, int y, int z) {
+        const long long ncell = (long long)gr.g[0] * gr.g[1] * gr.g[2];
+        (void)ncell;
+        const int c0 = AMVS_IDX((z * gr.g[1] + y) * gr.g[0] + x_first, ncell);
+        const int c1 = AMVS_IDX((z * gr.g[1] + y) * gr.g[0] + x_last, ncell);
+        const int b = AMVS_IDX(start[c0], n + 1), e = AMVS_IDX(start[c1 + 1], n + 1);
         for (int p = b; p < e; ++p) {
             const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
                          dz = qz - sorted[3 * (long long)p + 2];
             const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
-            if (d2 < worst) {
-                // replace one entry equal to the current largest, then find the new largest
-                bool done = false;
-                double w = -1.0;
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    const bool hit = !done & (best[j] == worst);
-                    best[j] = hit ? d2 : best[j];
-                    done |= hit;
-                    w = best[j] > w ? best[j] : w;
-                }
-                worst = w;
-            }
+            if (d2 < worst) knn_insert<K>(best, worst, d2);
         }
     };
 
@@ -170,10 +182,10 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
             for (int y = y0; y <= y1; ++y) {
                 const bool face = abs(z - cz) == r || abs(y - cy) == r;
                 if (face) {
-                    for (int x = x0; x <= x1; ++x) visit_cell(x, y, z);
+                    visit_row(x0, x1, y, z);
                 } else {                     // interior rows of the shell: only its two x faces
-                    if (cx - r >= 0) visit_cell(cx - r, y, z);
-                    if (r > 0 && cx + r < gr.g[0]) visit_cell(cx + r, y, z);
+                    if (cx - r >= 0) visit_row(cx - r, cx - r, y, z);
+                    if (r > 0 && cx + r < gr.g[0]) visit_row(cx + r, cx + r, y, z);
                 }
             }
         // every unvisited point lies at least r*h away (slightly shrunk against rounding of the binning)
@@ -183,15 +195,7 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
     if (!done && rmax >= gmax) done = true;        // every cell was visited
     if (!done) return;                             // stays pending: knn_box_kernel takes it
 
-    // ascending order, sqrt, drop the first (the query itself), numpy-order mean of the other K-1
-#pragma unroll
-    for (int i = 1; i < K; ++i)
-#pragma unroll
-        for (int j = K - 1; j >= i; --j) {
-            const double a = best[j - 1], b = best[j];
-            best[j - 1] = a < b ? a : b;
-            best[j] = a < b ? b : a;
-        }
+    // (ascending already) sqrt, drop the first (the query itself), numpy-order mean of the other K-1
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = sqrt(best[j]);
     mean_out[self] = numpy_pairwise_sum<K - 1>(best, 1) / (double)(K - 1);
@@ -230,39 +234,35 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
         for (int j = 0; j < K; ++j) best[j] = __builtin_inf();
         double worst = __builtin_inf();
         const int ny = y1 - y0 + 1, rows = ny * (z1 - z0 + 1);
-        for (int row = wave; row < rows; row += 4) {
-            const int z = z0 + row / ny, y = y0 + row % ny;
-            const long long base = ((long long)z * gr.g[1] + y) * gr.g[0];
-            const long long cells1 = (long long)gr.g[0] * gr.g[1] * gr.g[2] + 1;       // entries of `start`
-            (void)cells1;
-            const int b = AMVS_IDX(start[AMVS_IDX(base + x0, cells1)], n + 1), e = AMVS_IDX(start[AMVS_IDX(base + x1 + 1, cells1)], n + 1);
-            for (int p = b + lane; p < e; p += 64) {
-                const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
-                             dz = qz - sorted[3 * (long long)p + 2];
-                const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
-                if (d2 < worst) {
-                    bool hit_done = false;
-                    double w = -1.0;
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        const bool hit = !hit_done & (best[j] == worst);
-                        best[j] = hit ? d2 : best[j];
-                        hit_done |= hit;
-                        w = best[j] > w ? best[j] : w;
-                    }
-                    worst = w;
+        // Rows of the box in batches of 64 per wave: lane l looks up the point range of row (batch + l) -- the
+        // look-ups of a batch are independent loads in flight together --, then the non-empty rows are scanned one
+        // after the other, lanes taking points.  (The boxes of the queries that end up here are sparse: a row-by-row
+        // walk spent its time waiting for one dependent pair of look-ups per row, 1 089 rows per wave at R = 16.)
+        for (int row0 = wave * 64; row0 < rows; row0 += 4 * 64) {
+            const int row = row0 + lane;
+            int b = 0, e = 0;
+            if (row < rows) {
+                const int z = z0 + row / ny, y = y0 + row % ny;
+                const long long base = ((long long)z * gr.g[1] + y) * gr.g[0];
+                const long long cells1 = (long long)gr.g[0] * gr.g[1] * gr.g[2] + 1;       // entries of `start`
+                (void)cells1;
+                b = AMVS_IDX(start[AMVS_IDX(base + x0, cells1)], n + 1);
+                e = AMVS_IDX(start[AMVS_IDX(base + x1 + 1, cells1)], n + 1);
+            }
+            unsigned long long todo = __ballot(e > b);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int rb = __shfl(b, src), re = __shfl(e, src);
+                for (int p = rb + lane; p < re; p += 64) {
+                    const double dx = qx - sorted[3 * (long long)p], dy = qy - sorted[3 * (long long)p + 1],
+                                 dz = qz - sorted[3 * (long long)p + 2];
+                    const double d2 = ((dx * dx) + (dy * dy)) + (dz * dz);
+                    if (d2 < worst) knn_insert<K>(best, worst, d2);
                 }
             }
         }
-        // own list ascending, then the K smallest of the block, one per round
-#pragma unroll
-        for (int i = 1; i < K; ++i)
-#pragma unroll
-            for (int j = K - 1; j >= i; --j) {
-                const double a = best[j - 1], b2 = best[j];
-                best[j - 1] = a < b2 ? a : b2;
-                best[j] = a < b2 ? b2 : a;
-            }
+        // (own lists are ascending) the K smallest of the block, one per round
         int head = 0;
         for (int t = 0; t < K; ++t) {
             double v = __builtin_inf();
@@ -325,6 +325,17 @@ __global__ __launch_bounds__(256) void knn_occupied_kernel(const int *__restrict
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
 }
 
+// every stride-th point of a device-resident cloud, packed (the box estimate's sample)
+__global__ __launch_bounds__(256) void knn_sample_kernel(const double *__restrict__ pts, long long stride, long long cnt,
+                                                         double *__restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cnt) return;
+    out[3 * j] = pts[3 * j * stride];
+    out[3 * j + 1] = pts[3 * j * stride + 1];
+    out[3 * j + 2] = pts[3 * j * stride + 2];
+}
+
 __global__ __launch_bounds__(256) void knn_iota_kernel(int *__restrict__ v, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -354,16 +365,26 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     // is computed to find -- would otherwise stretch the box until the body of the cloud falls into a
     // few crowded cells.
     double lo[3], hi[3];
+    constexpr bool debug = AMVS_KNN_DEBUG;   // stage timings (development aid)
+    auto now_ms = []() {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t_begin = debug ? now_ms() : 0.0;
     {
-        const long long stride = std::max<long long>(1, n / 65536);
+        const long long stride = std::max<long long>(1, n / 16384);
         const long long cnt = (n + stride - 1) / stride;
-        // the strided sample on the host (a device-resident cloud is sampled with one strided copy:
-        // dereferencing device memory from the host works through the PCIe BAR but takes ~4 us per read)
+        // the strided sample on the host
         std::vector<double> sample((size_t)(3 * cnt));
         if (points_on_device) {
-            hipError_t e = hipMemcpy2DAsync(sample.data(), 24, points, (size_t)stride * 24, 24, (size_t)cnt,
-                                            hipMemcpyDeviceToHost, st);
+            // gathered on the device, then ONE contiguous copy (a strided hipMemcpy2D of 65 536 rows of 24 bytes took
+            // 2 ms; dereferencing device memory from the host works through the PCIe BAR but takes ~4 us per read)
+            double *d_sample = nullptr;
+            KCHK(pool_malloc(&d_sample, sizeof(double) * 3 * (size_t)cnt));
+            hipLaunchKernelGGL(knn_sample_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, points, stride, cnt, d_sample);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(sample.data(), d_sample, sizeof(double) * 3 * (size_t)cnt, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
+            pool_free(d_sample);
             if (e != hipSuccess) return e;
         } else {
             for (long long j = 0; j < cnt; ++j)
@@ -392,6 +413,7 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     const double h_min = emax / (KNN_GMAX - 2);      // keeps every in-box cell index below KNN_GMAX
     h = std::max(h, h_min);
 
+    const double t_sampled = debug ? now_ms() : 0.0;
     double *d_pts = nullptr, *d_sorted = nullptr, *d_mean = nullptr;
     int *d_cell = nullptr, *d_count = nullptr, *d_start = nullptr, *d_origin = nullptr;
     unsigned char *d_pending = nullptr;
@@ -402,20 +424,20 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     auto cleanup = [&]() {
         for (void *p : {(void *)d_pts, (void *)d_sorted, (void *)d_mean, (void *)d_cell, (void *)d_count,
                         (void *)d_start, (void *)d_origin, (void *)d_pending, (void *)d_occ, d_tmp})
-            if (p) (void)hipFree(p);
+            if (p) pool_free(p);
     };
 #define KCHK_C(call)                                                   \
     do {                                                               \
         hipError_t e_ = (call);                                        \
         if (e_ != hipSuccess) { cleanup(); return e_; }                \
     } while (0)
-    KCHK_C(hipMalloc(&d_pts, sizeof(double) * 3 * n));
-    KCHK_C(hipMalloc(&d_sorted, sizeof(double) * 3 * n));
-    KCHK_C(hipMalloc(&d_mean, sizeof(double) * n));
-    KCHK_C(hipMalloc(&d_cell, sizeof(int) * n));
-    KCHK_C(hipMalloc(&d_origin, sizeof(int) * n));
-    KCHK_C(hipMalloc(&d_pending, (size_t)n));
-    KCHK_C(hipMalloc(&d_occ, sizeof(int)));
+    KCHK_C(pool_malloc(&d_pts, sizeof(double) * 3 * n));
+    KCHK_C(pool_malloc(&d_sorted, sizeof(double) * 3 * n));
+    KCHK_C(pool_malloc(&d_mean, sizeof(double) * n));
+    KCHK_C(pool_malloc(&d_cell, sizeof(int) * n));
+    KCHK_C(pool_malloc(&d_origin, sizeof(int) * n));
+    KCHK_C(pool_malloc(&d_pending, (size_t)n));
+    KCHK_C(pool_malloc(&d_occ, sizeof(int)));
     KCHK_C(hipMemcpyAsync(d_pts, points, sizeof(double) * 3 * n,
                           points_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     KCHK_C(hipMemsetAsync(d_pending, 1, (size_t)n, st));
@@ -430,11 +452,11 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         for (int a = 0; a < 3; ++a) gr.g[a] = std::max(1, std::min(KNN_GMAX, (int)std::floor(ext[a] / edge) + 1));
         cells = (long long)gr.g[0] * gr.g[1] * gr.g[2];
         if (cells + 1 > table_cap) {
-            if (d_count) (void)hipFree(d_count);
-            if (d_start) (void)hipFree(d_start);
+            if (d_count) pool_free(d_count);
+            if (d_start) pool_free(d_start);
             d_count = d_start = nullptr;
-            KCHK(hipMalloc(&d_count, sizeof(int) * (cells + 1)));
-            KCHK(hipMalloc(&d_start, sizeof(int) * (cells + 1)));
+            KCHK(pool_malloc(&d_count, sizeof(int) * (cells + 1)));
+            KCHK(pool_malloc(&d_start, sizeof(int) * (cells + 1)));
             table_cap = cells + 1;
         }
         KCHK(hipMemsetAsync(d_count, 0, sizeof(int) * (cells + 1), st));
@@ -443,9 +465,9 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         size_t need = 0;
         KCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, d_count, d_start, (int)(cells + 1), st));
         if (need > tmp_bytes) {
-            if (d_tmp) (void)hipFree(d_tmp);
+            if (d_tmp) pool_free(d_tmp);
             d_tmp = nullptr;
-            KCHK(hipMalloc(&d_tmp, need));
+            KCHK(pool_malloc(&d_tmp, need));
             tmp_bytes = need;
         }
         KCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_count, d_start, (int)(cells + 1), st));
@@ -477,9 +499,11 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     };
 
     // level 0: edge fitted to the occupancy of the occupied cells (3 .. 24 points)
+    double fitted_per_cell = 0.0;
     for (int attempt = 0; attempt < 6; ++attempt) {
         double per_cell = 0.0;
         KCHK_C(bin(h, per_cell));
+        fitted_per_cell = per_cell;
         const bool at_limit = gr.g[0] == KNN_GMAX || gr.g[1] == KNN_GMAX || gr.g[2] == KNN_GMAX;
         if (per_cell > 24.0 && !at_limit && h > h_min) { h = std::max(h * 0.5, h_min); continue; }
         if (per_cell < 3.0 && cells > 1) { h *= 2.0; continue; }
@@ -487,11 +511,11 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     }
     // coarser levels (edge x2 each) pick up the queries whose neighbourhood is sparser than two
     // shells of the level before; the last level may scan
-    constexpr bool debug = AMVS_KNN_DEBUG;   // stage timings (development aid)
+    const double t_binned = debug ? ((void)hipStreamSynchronize(st), now_ms()) : 0.0;
     int *d_iota = nullptr, *d_queries = nullptr, *d_nsel = nullptr;
     auto cleanup2 = [&]() {
         for (void *p : {(void *)d_iota, (void *)d_queries, (void *)d_nsel})
-            if (p) (void)hipFree(p);
+            if (p) pool_free(p);
         d_iota = d_queries = d_nsel = nullptr;
     };
 #define KCHK_D(call)                                                   \
@@ -499,9 +523,9 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         hipError_t e_ = (call);                                        \
         if (e_ != hipSuccess) { cleanup2(); cleanup(); return e_; }    \
     } while (0)
-    KCHK_D(hipMalloc(&d_iota, sizeof(int) * n));
-    KCHK_D(hipMalloc(&d_queries, sizeof(int) * n));
-    KCHK_D(hipMalloc(&d_nsel, sizeof(int)));
+    KCHK_D(pool_malloc(&d_iota, sizeof(int) * n));
+    KCHK_D(pool_malloc(&d_queries, sizeof(int) * n));
+    KCHK_D(pool_malloc(&d_nsel, sizeof(int)));
     hipLaunchKernelGGL(knn_iota_kernel, dim3(bx), dim3(256), 0, st, d_iota, n);
     KCHK_D(hipGetLastError());
     // the still-pending queries, compacted (and counted) after every level
@@ -509,9 +533,9 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
         size_t need = 0;
         KCHK(hipcub::DeviceSelect::Flagged(nullptr, need, d_iota, d_pending, d_queries, d_nsel, (int)n, st));
         if (need > tmp_bytes) {
-            if (d_tmp) (void)hipFree(d_tmp);
+            if (d_tmp) pool_free(d_tmp);
             d_tmp = nullptr;
-            KCHK(hipMalloc(&d_tmp, need));
+            KCHK(pool_malloc(&d_tmp, need));
             tmp_bytes = need;
         }
         KCHK(hipcub::DeviceSelect::Flagged(d_tmp, tmp_bytes, d_iota, d_pending, d_queries, d_nsel, (int)n, st));
@@ -545,15 +569,20 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
             float ms0 = 0.f, ms1 = 0.f;
             (void)hipEventElapsedTime(&ms0, e0, e1);
             (void)hipEventElapsedTime(&ms1, e1, e2);
-            std::fprintf(stderr, "knn: h %.4g grid %dx%dx%d  cell walk %.2f ms, %d of %lld pending -> box scans %.2f ms\n", gr.h,
-                         gr.g[0], gr.g[1], gr.g[2], ms0, left, n, ms1);
+            std::fprintf(stderr, "knn: h %.4g grid %dx%dx%d (%.1f points per occupied cell)  cell walk %.2f ms, %d of %lld pending -> box scans %.2f ms\n", gr.h,
+                         gr.g[0], gr.g[1], gr.g[2], fitted_per_cell, ms0, left, n, ms1);
         }
     }
+    const double t_searched = debug ? ((void)hipStreamSynchronize(st), now_ms()) : 0.0;
     cleanup2();
 #undef KCHK_D
     KCHK_C(hipMemcpyAsync(mean_out, d_mean, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     KCHK_C(hipStreamSynchronize(st));
+    const double t_copied = debug ? now_ms() : 0.0;
     cleanup();
+    if (debug)
+        std::fprintf(stderr, "knn: box sample %.2f ms, allocate + bin %.2f, search %.2f, result to the host %.2f, release %.2f\n",
+                     t_sampled - t_begin, t_binned - t_sampled, t_searched - t_binned, t_copied - t_searched, now_ms() - t_copied);
     return hipSuccess;
 #undef KCHK_C
 }

@@ -10,7 +10,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/3d-reconstruction-tool_amd/csrc
 out=$root/build/variants; mkdir -p $out/obj_$name
 flags="--offload-arch=${ARCH:-gfx950} -O3 -ffp-contract=off -fPIC -std=c++17 -fvisibility=hidden -Wall -Wno-unused-result"
-for f in amvs_kernels amvs_kernels_fast amvs_sweep_fast amvs_sweep_exact amvs_generic amvs_capi amvs_fusion amvs_knn amvs_prep amvs_extended; do
+for f in amvs_kernels amvs_kernels_fast amvs_sweep_fast amvs_sweep_exact amvs_generic amvs_capi amvs_fusion amvs_knn amvs_prep amvs_extended amvs_pool; do
   if [ $f = amvs_kernels_fast ] || [ $f = amvs_sweep_fast ] || { [ $f = amvs_sweep_exact ] && [ -z "$FAST_ONLY" ]; } || { [ $f = amvs_kernels ] && [ -z "$FAST_ONLY" ]; } || [ -n "$ALL" ] || [ ! -f $src/$f.o ]; then
     extra=""; { [ $f = amvs_sweep_fast ] || [ $f = amvs_sweep_exact ]; } && extra="-mllvm -amdgpu-sched-strategy=iterative-maxocc"    # as csrc/Makefile
     /opt/rocm/bin/hipcc $flags $extra "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
