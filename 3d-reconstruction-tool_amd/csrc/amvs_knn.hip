@@ -12,10 +12,10 @@
 // The values do not depend on how ties are broken, so any exact k-nearest search gives them.  The
 // search here: points are binned into a uniform grid over the 1st-99th percentile box (counting
 // sort, cell edge h fitted to the occupancy); a thread per point visits the cells of Chebyshev shells
-// 0..2 around its own cell and is done after shell r once its k-th smallest squared distance is
-// <= (r*h)^2 (everything not yet visited is farther); a query left pending gets one block that scans
-// the box of cells within R = 4, 8, 16, ... shells cooperatively (knn_box_kernel) until the same rule
-// holds or the box is the whole grid.
+// 0..1 around its own cell and is done after shell r once its k-th smallest squared distance is
+// <= (r*h)^2 (everything not yet visited is farther); a query left pending gets a wave that scans the box of
+// cells within R = 2 shells cooperatively, and if the rule still fails a block that scans the boxes R = 4, 8,
+// 16, ... (knn_box_kernel) until it holds or the box is the whole grid.
 #define AMVS_TU_ID 8
 #include "amvs_check.h"
 #include "amvs_kernels.h"
@@ -211,18 +211,22 @@ __global__ __launch_bounds__(128) void knn_query_kernel(const double *__restrict
 // <= R h.  If not, R doubles; a box that covers the grid is a full scan.  A single thread walking a
 // coarser grid took ~1.2 us per query and the coarser grids had to be re-binned (6-7 ms each on a
 // 277 k-point cloud); this takes one launch.
-template <int K>
-__global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__ pts, const double *__restrict__ sorted,
-                                                      Grid gr, const int *__restrict__ start, int r_first,
-                                                      const int *__restrict__ queries, unsigned char *__restrict__ pending,
-                                                      double *__restrict__ mean_out, long long n)
+// NW = waves per block: 4 for the doubling boxes; ONE for the first cooperative pass, the box R = 2 (r_last = 2: a
+// query it does not settle stays pending) -- the cells a single thread's walk would visit as shells 0..2, but scanned
+// by 64 lanes: on the stereo path's cloud 12 % of the queries need shell 2, many of them next to crowded cells, and a
+// thread walking 45 rows of up to hundreds of points each held its whole wave for 5 ms.
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW) void knn_box_kernel(const double *__restrict__ pts, const double *__restrict__ sorted,
+                                                          Grid gr, const int *__restrict__ start, int r_first, int r_last,
+                                                          const int *__restrict__ queries, unsigned char *__restrict__ pending,
+                                                          double *__restrict__ mean_out, long long n)
 {
     const int self = AMVS_IDX(queries[blockIdx.x], n);
     const double qx = pts[3 * (long long)self], qy = pts[3 * (long long)self + 1], qz = pts[3 * (long long)self + 2];
     const int cx = cell_of(gr, qx, 0), cy = cell_of(gr, qy, 1), cz = cell_of(gr, qz, 2);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ double red_v[4];
-    __shared__ int red_t[4];
+    __shared__ double red_v[NW];
+    __shared__ int red_t[NW];
     __shared__ double out[KNN_KMAX];
     for (int R = r_first;; R *= 2) {
         const int x0 = max(cx - R, 0), x1 = min(cx + R, gr.g[0] - 1);
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
         // look-ups of a batch are independent loads in flight together --, then the non-empty rows are scanned one
         // after the other, lanes taking points.  (The boxes of the queries that end up here are sparse: a row-by-row
         // walk spent its time waiting for one dependent pair of look-ups per row, 1 089 rows per wave at R = 16.)
-        for (int row0 = wave * 64; row0 < rows; row0 += 4 * 64) {
+        for (int row0 = wave * 64; row0 < rows; row0 += NW * 64) {
             const int row = row0 + lane;
             int b = 0, e = 0;
             if (row < rows) {
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
             double bv = red_v[0];
             int bt = red_t[0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const bool take = (red_v[w] < bv) | ((red_v[w] == bv) & (red_t[w] < bt));
                 bv = take ? red_v[w] : bv;
                 bt = take ? red_t[w] : bt;
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
         }
         const double reach = (double)R * gr.h * (1.0 - 1e-9);
         if (whole || out[K - 1] <= reach * reach) break;         // block-uniform: `out` is shared
+        if (R >= r_last) return;                                 // (block-uniform too) stays pending
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -305,11 +310,15 @@ __global__ __launch_bounds__(256) void knn_box_kernel(const double *__restrict__
 }
 
 template <int K>
-hipError_t launch_box(const double *pts, const double *sorted, const Grid &gr, const int *start, int r_first,
+hipError_t launch_box(const double *pts, const double *sorted, const Grid &gr, const int *start, int r_first, int r_last,
                       const int *queries, int n_queries, unsigned char *pending, double *mean_out, long long n, hipStream_t st)
 {
-    hipLaunchKernelGGL((knn_box_kernel<K>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, sorted, gr, start, r_first,
-                       queries, pending, mean_out, n);
+    if (r_last <= r_first)        // the single-box pass: a wave per query
+        hipLaunchKernelGGL((knn_box_kernel<K, 1>), dim3((unsigned)n_queries), dim3(64), 0, st, pts, sorted, gr, start, r_first,
+                           r_last, queries, pending, mean_out, n);
+    else
+        hipLaunchKernelGGL((knn_box_kernel<K, 4>), dim3((unsigned)n_queries), dim3(256), 0, st, pts, sorted, gr, start, r_first,
+                           r_last, queries, pending, mean_out, n);
     return hipGetLastError();
 }
 
@@ -500,6 +509,7 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
 
     // level 0: edge fitted to the occupancy of the occupied cells (3 .. 24 points)
     double fitted_per_cell = 0.0;
+    int walk_again = 0;
     for (int attempt = 0; attempt < 6; ++attempt) {
         double per_cell = 0.0;
         KCHK_C(bin(h, per_cell));
@@ -547,30 +557,36 @@ hipError_t knn_mean_distance(const double *points, long long n, int k, double *m
     {
         hipEvent_t e0, e1, e2;
         if (debug) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2); (void)hipEventRecord(e0, st); }
-        KCHK_D(query(KNN_SHELLS));
-        KCHK_D(pending_list(left));
-        if (debug) (void)hipEventRecord(e1, st);
-        if (left > 0) {
-            hipError_t e = hipErrorInvalidValue;
-            const int r_first = 2 * KNN_SHELLS;
+        auto box = [&](int r_first, int r_last, int count) -> hipError_t {
             switch (k) {
-            case 8: e = launch_box<8>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
-            case 10: e = launch_box<10>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
-            case 16: e = launch_box<16>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
-            case 20: e = launch_box<20>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
-            case 32: e = launch_box<32>(d_pts, d_sorted, gr, d_start, r_first, d_queries, left, d_pending, d_mean, n, st); break;
-            default: break;
+            case 8: return launch_box<8>(d_pts, d_sorted, gr, d_start, r_first, r_last, d_queries, count, d_pending, d_mean, n, st);
+            case 10: return launch_box<10>(d_pts, d_sorted, gr, d_start, r_first, r_last, d_queries, count, d_pending, d_mean, n, st);
+            case 16: return launch_box<16>(d_pts, d_sorted, gr, d_start, r_first, r_last, d_queries, count, d_pending, d_mean, n, st);
+            case 20: return launch_box<20>(d_pts, d_sorted, gr, d_start, r_first, r_last, d_queries, count, d_pending, d_mean, n, st);
+            case 32: return launch_box<32>(d_pts, d_sorted, gr, d_start, r_first, r_last, d_queries, count, d_pending, d_mean, n, st);
+            default: return hipErrorInvalidValue;
             }
-            KCHK_D(e);
+        };
+        // a thread per query walks shells 0..1; a wave per query left scans the box R = 2 (the cells of shells
+        // 0..2); a block per query still left scans the boxes R = 4, 8, ... until its rule holds
+        KCHK_D(query(1));
+        KCHK_D(pending_list(left));
+        walk_again = left;
+        if (left > 0) {
+            KCHK_D(box(KNN_SHELLS, KNN_SHELLS, left));
+            KCHK_D(pending_list(left));
         }
+        if (debug) (void)hipEventRecord(e1, st);
+        if (left > 0) KCHK_D(box(2 * KNN_SHELLS, 1 << 30, left));     // (R = 4 as a wave's pass of its own: no gain, measured)
         if (debug) {
             (void)hipEventRecord(e2, st);
             (void)hipStreamSynchronize(st);
             float ms0 = 0.f, ms1 = 0.f;
             (void)hipEventElapsedTime(&ms0, e0, e1);
             (void)hipEventElapsedTime(&ms1, e1, e2);
-            std::fprintf(stderr, "knn: h %.4g grid %dx%dx%d (%.1f points per occupied cell)  cell walk %.2f ms, %d of %lld pending -> box scans %.2f ms\n", gr.h,
-                         gr.g[0], gr.g[1], gr.g[2], fitted_per_cell, ms0, left, n, ms1);
+            std::fprintf(stderr, "knn: h %.4g grid %dx%dx%d (%.1f points per occupied cell)  cell walk + box 2: %.2f ms (%d queries to the box), "
+                         "%d of %lld pending -> boxes 4, 8, ...: %.2f ms\n", gr.h, gr.g[0], gr.g[1], gr.g[2], fitted_per_cell, ms0, walk_again,
+                         left, n, ms1);
         }
     }
     const double t_searched = debug ? ((void)hipStreamSynchronize(st), now_ms()) : 0.0;

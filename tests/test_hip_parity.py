@@ -571,7 +571,7 @@ def test_knn_mean_distance_matches_sklearn(eng_a):
     scikit-learn kneighbors + np.mean over distances[:, 1:]): bit-identical float64."""
     NearestNeighbors = pytest.importorskip("sklearn.neighbors").NearestNeighbors
     for name, pts in _knn_clouds().items():
-        for k in ((20, 8) if name == "sheets" else (20,)):
+        for k in {"sheets": (20, 8), "duplicates+outliers": (20, 10, 16, 32), "cluster+halo": (20, 32)}.get(name, (20,)):
             dists, _ = NearestNeighbors(n_neighbors=k).fit(pts).kneighbors(pts)
             want = np.mean(dists[:, 1:], axis=1)
             got = eng_a.knn_mean_distance(pts, k)
