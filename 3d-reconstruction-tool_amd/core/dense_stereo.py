@@ -36,6 +36,9 @@ def _torch_cuda():
     return torch if torch.cuda.is_available() else None
 
 
+_DRAW_BUF = None            # (arange, scratch) of DenseStereoReconstructor._draw_without_replacement
+
+
 class DenseStereoReconstructor:
     NUM_NEIGHBORS = 6        # reference :109
 
@@ -219,7 +222,7 @@ class DenseStereoReconstructor:
             # the reference sub-samples clouds above 500 000 points at random (unseeded np.random.choice, :449-451)
             # and filters the sample: the same draw, the sample taken on the device (amvs_cloud_take), so that the
             # cloud never travels to the host -- the same points as the host path returns for the same draw
-            chosen = np.random.choice(total, 500000, replace=False)
+            chosen = self._draw_without_replacement(total, 500000)
             total = eng.cloud_take(chosen)
             mean_d = eng.cloud_knn_mean_distance(total, k)
             keep = mean_d < np.mean(mean_d) + std_ratio * np.std(mean_d)
@@ -237,6 +240,25 @@ class DenseStereoReconstructor:
         m = eng.cloud_voxel_downsample(voxel_size, keep)
         print(f"  After voxel downsample: {m:,}")
         return eng.fetch_cloud(m)
+
+    def _draw_without_replacement(self, total: int, size: int) -> np.ndarray:
+        """`np.random.choice(total, size, replace=False)` -- the reference's unseeded draw (dense_stereo.py:449-451) --
+        made in buffers the module keeps.  NumPy's legacy generator defines that call as `permutation(total)[:size]`
+        and `permutation(n)` as `arange(n)` shuffled in place, so shuffling a kept copy of `arange(total)` consumes the
+        global generator identically and returns the same indices (checked against np.random.choice in
+        tests/test_host_logic.py).  Why: the 4.8 MB array a fresh `choice` allocates is handed to the driver's
+        host-to-device copy straight after it is written, and on this platform such a copy from a just-mapped host
+        range takes 13-24 ms instead of 0.1 ms in every second call or so (measured); a buffer
+        that is reused does not show it."""
+        global _DRAW_BUF                              # one pair of buffers per process
+        buf = _DRAW_BUF
+        if buf is None or buf[0].size < total:
+            cap = max(int(total), 1 << 20)
+            buf = _DRAW_BUF = (np.arange(cap, dtype=np.int64), np.empty(cap, np.int64))
+        idx = buf[1][:total]
+        np.copyto(idx, buf[0][:total])
+        np.random.shuffle(idx)
+        return idx[:size]
 
     # ------------------------------------------------------------------ host ------
     def _prepare_images(self, images: List[dict], indices: List[int]) -> Dict:

@@ -749,9 +749,9 @@ def run_patchmatch_single(sc, sources, ids, H, W, mode, patch, iters, samples, s
 
 
 # The end-to-end records time FIVE calls after the first and report the median one (all five are listed): on this
-# driver a host mmap / munmap of a multi-megabyte array (np.random.choice's permutation, any array glibc serves
-# from or returns to the system) within a few milliseconds of a GPU submission can hold that submission for 15-30 ms
-#  -- most often in the first calls of a process, before glibc's thresholds have adapted.
+# platform a pageable host-to-device copy issued right after the host process mapped or unmapped a multi-megabyte
+# array can take 15-30 ms instead of 0.1 ms (the stereo class no longer provokes it, a host
+# application's own allocations still can).
 CLI_TIMED_CALLS = 5
 CLI_TIMED_NOTE = "median of 5 calls after the first (each listed in timed_calls_s)"
 

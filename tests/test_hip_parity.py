@@ -623,21 +623,28 @@ def test_stereo_reconstruct_device_filter_equals_sklearn_filter(amvs_mod):
 
 def test_stereo_big_cloud_random_subsample_on_the_device(amvs_mod, monkeypatch, capsys):
     """Round 4: clouds above 500 000 points, which the reference sub-samples with an unseeded np.random.choice before
-    its outlier filter (dense_stereo.py:449-451).  The class makes the same draw and takes the sample on the device
-    (amvs_cloud_take), so the 2 M-point cloud never travels to the host; for the SAME draw it must return exactly
-    the cloud of the host path (fetch, points[chosen], neighbour statistic, numpy selection, numpy voxel grid)."""
+    its outlier filter (dense_stereo.py:449-451).  The class makes the same draw (in kept buffers: the indices
+    np.random.choice returns for the same generator state, tests/test_host_logic.py) and takes the sample on the device
+    (amvs_cloud_take), so the 2 M-point cloud never travels to the host; for the SAME generator state it must return
+    exactly the cloud of the host path, which calls np.random.choice itself as the reference does (fetch,
+    points[chosen], neighbour statistic, numpy selection, numpy voxel grid)."""
     import torch
     from amvs.synthetic import make_scene
     sc = make_scene(12, 756, 1008, seed=8, device="cuda" if torch.cuda.is_available() else "cpu")
     images = sc.images()
     cam = amvs_mod.Camera(K=sc.camera.K.copy(), dist=np.zeros(5))
     draws = []
-    real_choice = np.random.choice
+    real_choice, real_shuffle = np.random.choice, np.random.shuffle
 
     def counting_choice(*a, **k):
-        draws.append(a[0])
+        draws.append(("choice", a[0]))
         return real_choice(*a, **k)
+
+    def counting_shuffle(x):
+        draws.append(("shuffle", len(x)))
+        return real_shuffle(x)
     monkeypatch.setattr(np.random, "choice", counting_choice)
+    monkeypatch.setattr(np.random, "shuffle", counting_shuffle)
     out = {}
     for where in ("device", "host"):
         ds = amvs_mod.DenseStereoReconstructor(cam, scale=1.0, num_depths=32, min_views=2)
@@ -646,7 +653,7 @@ def test_stereo_big_cloud_random_subsample_on_the_device(amvs_mod, monkeypatch, 
         out[where] = ds.reconstruct(images, sc.poses)
         ds._engine.close()
     capsys.readouterr()
-    assert len(draws) == 2 and draws[0] == draws[1] and draws[0] > 500000, draws
+    assert len(draws) == 2 and draws[0][0] == "shuffle" and draws[1][0] == "choice" and draws[0][1] == draws[1][1] > 500000, draws
     assert len(out["device"][0]) > 10000
     assert np.array_equal(out["device"][0], out["host"][0]) and np.array_equal(out["device"][1], out["host"][1])
     # the entry point refuses indices outside the resident cloud

@@ -340,3 +340,19 @@ def test_native_exchange_without_rccl_is_unsupported_not_fatal():
     lines = out.stdout.strip().splitlines()
     assert lines[0] == "-3" and lines[-1] == "-3", out.stdout          # AMVS_EUNSUPPORTED, twice
     assert "RCCL not found" in lines[1] and "/nonexistent/librccl.so.1" in lines[1]
+
+
+def test_stereo_subsample_draw_equals_numpy_choice():
+    """DenseStereoReconstructor's draw for clouds above 500 000 points is np.random.choice(total, size, replace=False)
+    (dense_stereo.py:449-451) index for index, and leaves NumPy's global generator in the same state -- made in kept
+    buffers (core/dense_stereo.py: _draw_without_replacement)."""
+    from amvs.core.dense_stereo import DenseStereoReconstructor
+    ds = DenseStereoReconstructor.__new__(DenseStereoReconstructor)
+    for total, size in ((603638, 500000), (500001, 500000), (1300003, 500000), (700000, 500000), (20, 7)):
+        np.random.seed(total % 1000)
+        want = np.random.choice(total, size, replace=False)
+        after_want = np.random.rand()
+        np.random.seed(total % 1000)
+        got = ds._draw_without_replacement(total, size)
+        after_got = np.random.rand()
+        assert got.dtype == want.dtype and np.array_equal(got, want) and after_got == after_want
