@@ -269,10 +269,12 @@ class DenseStereoReconstructor:
         convert there; the engine is cached for the returned dict ('gray' is None)."""
         h, w = images[indices[0]]["image"].shape[:2]
         H, W = int(h * self.scale), int(w * self.scale)
-        if self._engine is not None:
-            self._engine.close()
-            self._engine = None
-        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id, mode=self.mode)
+        eng = self._engine
+        if eng is None or not eng.reusable_for(H, W, len(indices), self.K_scaled, self.device_id, self.mode):
+            if eng is not None:
+                eng.close()
+                self._engine = None
+            eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id, mode=self.mode)
         self._slot = {idx: s for s, idx in enumerate(indices)}
         prepared = {}
         for idx in indices:

@@ -228,10 +228,12 @@ class PatchMatchMVS:
         Returns the prepared dict without host gray maps ('gray': None); the engine is cached for it."""
         h, w = images[indices[0]]["image"].shape[:2]
         H, W = int(h * self.scale), int(w * self.scale)
-        if self._engine is not None:
-            self._engine.close()
-            self._engine = None
-        eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id)
+        eng = self._engine
+        if eng is None or not eng.reusable_for(H, W, len(indices), self.K_scaled, self.device_id):
+            if eng is not None:
+                eng.close()
+                self._engine = None
+            eng = _engine.Engine(H, W, len(indices), self.K_scaled.astype(np.float32), device=self.device_id)
         self._slot = {idx: s for s, idx in enumerate(indices)}
         prepared = {}
         for idx in indices:

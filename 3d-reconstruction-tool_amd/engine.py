@@ -65,6 +65,12 @@ class Engine:
         if mode != "exact":
             self.set_mode(mode)
 
+    def reusable_for(self, H, W, n_views, K, device, mode="exact"):
+        """True if this (open) context was created for exactly this problem: the classes then upload the next call's
+        views into it instead of destroying and re-creating it (some twenty device buffers: 1.5 ms a call)."""
+        return (self._h is not None and (self.H, self.W, self.n_views, self.device) == (int(H), int(W), int(n_views), int(device))
+                and np.array_equal(self.K, np.asarray(K, np.float32).reshape(3, 3)) and self.mode() == mode)
+
     # -- arithmetic mode ------------------------------------------------------
     def set_mode(self, mode):
         """'exact' (bit-identical to the reference's float32 chain) or 'fast' (tolerance mode,
