@@ -21,6 +21,7 @@ if [ -z "$SKIP_FUZZ" ]; then
 AMVS_BENCH_BACKEND=gloo AMVS_BENCH_ONE_DEVICE=1 timeout -k 10 600 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse.log 2>&1 || { tail -5 gpurun_out/rehearse.log; exit 1; }
 timeout -k 10 600 python tools/fuzz_parity.py --cases 80 > gpurun_out/fuzz_pm.log 2>&1 || { tail -3 gpurun_out/fuzz_pm.log; exit 1; }
 timeout -k 10 600 python tools/fuzz_parity.py --sweep --cases 80 > gpurun_out/fuzz_ps.log 2>&1 || { tail -3 gpurun_out/fuzz_ps.log; exit 1; }
-tail -1 gpurun_out/fuzz_pm.log; tail -1 gpurun_out/fuzz_ps.log
+timeout -k 10 600 python tools/fuzz_knn.py --cases 40 > gpurun_out/fuzz_knn.log 2>&1 || { tail -3 gpurun_out/fuzz_knn.log; exit 1; }
+tail -1 gpurun_out/fuzz_pm.log; tail -1 gpurun_out/fuzz_ps.log; tail -1 gpurun_out/fuzz_knn.log
 fi
 echo cycle-ok
