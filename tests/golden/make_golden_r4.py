@@ -12,6 +12,14 @@ dense_stereo.py:36, :325-341); these fixtures pin the patch sizes that run on th
     g19_patch_cost_k13_15   _compute_patch_cost for patch sizes 13 and 15 (scene A, S = 4, g03's depth map)
     g20_patchmatch_k13      _patchmatch_cuda with patch 13, 3 iterations x 4 samples, one view of scene D
     g21_plane_sweep_k13     _plane_sweep_torch with patch 13, 6 neighbours, 16 planes (scene D)
+
+and the operating points of the reference's CLI (run_reconstruction.py:131-136, :150-154), which the classes'
+defaults reproduce:
+
+    g22_patchmatch_cli      _patchmatch_cuda with the constructor defaults the CLI leaves alone -- patch 11, 8 samples --
+                            and its num_iterations = 3, two views of scene D
+    g23_plane_sweep_cli     _plane_sweep_torch with DenseStereoReconstructor's defaults: 64 planes, patch 5, 6
+                            neighbours, threshold 0.8 (scene D)
 """
 import os
 import sys
@@ -68,6 +76,29 @@ def main():
     dmap, conf, _ = dsD._plane_sweep_torch(scD.grays[3], scD.colors[3], posesD[3], nbrs, procD, posesD,
                                            depths, 56, 72)
     mg.save("g21_plane_sweep_k13", ref=3, nbrs=np.array(nbrs), depths=depths, patch=13, thresh=0.8,
+            depth_map=dmap, confidence=conf)
+
+    # ---- g22: the CLI's PatchMatch operating point (patch 11, 3 iterations x 8 samples) ----------
+    pmC = mg.ref_pm(scD, 11, 3, 8)
+    out = {}
+    for r in (1, 4):
+        srcs = pmC._select_source_views(r, sorted(posesD), posesD, k=4)
+        inj = mg.InjectedRng(SEED, r, 0, with_init=True)
+        with mg.injected(inj):
+            dm = pmC._patchmatch_cuda(r, srcs, procD, posesD)
+        assert inj.draw == 1 + 3 * 8
+        out.update({f"srcs_{r}": np.array(srcs), f"depth_{r}": dm.depth, f"normal_{r}": dm.normal,
+                    f"confidence_{r}": dm.confidence})
+    mg.save("g22_patchmatch_cli", refs=np.array([1, 4]), patch=11, iters=3, samples=8, seed=SEED, **out)
+
+    # ---- g23: the stereo class's defaults (64 planes, patch 5, 6 neighbours) ----------------------
+    dsC = stereo.DenseStereoReconstructor(refcam.Camera(K=scD.camera.K.copy(), dist=np.zeros(5)), scale=1.0)
+    assert (dsC.num_depths, dsC.patch_size, dsC.consistency_thresh) == (64, 5, 0.8)
+    nbrs = dsC._find_neighbors(2, sorted(posesD), posesD, k=6)
+    depths = 1.0 / np.linspace(1 / scD.depth_max, 1 / scD.depth_min, dsC.num_depths)
+    dmap, conf, _ = dsC._plane_sweep_torch(scD.grays[2], scD.colors[2], posesD[2], nbrs, procD, posesD,
+                                           depths, 56, 72)
+    mg.save("g23_plane_sweep_cli", ref=2, nbrs=np.array(nbrs), depths=depths, patch=5, thresh=0.8,
             depth_map=dmap, confidence=conf)
 
 

@@ -250,3 +250,35 @@ def test_classes_accept_any_odd_patch_size(scene_b, capsys, patch):
         for bad in (6, 33, 1):
             with pytest.raises(AmvsError, match="patch_size"):
                 eng.eval_cost(1, [0, 2], bad, scene_b.gt_depth[1])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cli_operating_points_bit_exact_and_reference_golden(scene_d, mode):
+    """The reference CLI's operating points (the classes' defaults): _patchmatch_cuda with patch 11, 3 iterations x
+    8 samples (g22) and _plane_sweep_torch with 64 planes, patch 5, 6 neighbours (g23) -- the HIP kernels bit-exact
+    against the oracle, and against the reference's own maps within the stated tolerances (measured: every depth
+    within 1e-3, 96 % identical, confidence identical)."""
+    from amvs.engine import make_pm_params
+    g = load_golden("g22_patchmatch_cli")
+    refs = [int(x) for x in g["refs"]]
+    srcs = [list(g[f"srcs_{r}"]) for r in refs]
+    k, iters, samples, seed = int(g["patch"]), int(g["iters"]), int(g["samples"]), int(g["seed"])
+    s23 = load_golden("g23_plane_sweep_cli")
+    planes = s23["depths"].astype(np.float32)
+    with scene_d.engine(mode) as eng:
+        depth, normal, conf = eng.patchmatch(refs, srcs, make_pm_params(k, iters, samples, scene_d.depth_min, scene_d.depth_max), seed)
+        sd, sc = eng.plane_sweep(int(s23["ref"]), list(s23["nbrs"]), planes, int(s23["patch"]), float(s23["thresh"]))
+    for i, r in enumerate(refs):
+        od, on, oc = scene_d.oracle_ctx(r, srcs[i], k, mode).patchmatch(iters, samples, scene_d.depth_min, scene_d.depth_max, seed, r)
+        _eq(depth[i], od, f"{mode} view {r} depth")
+        _eq(conf[i], oc, f"{mode} view {r} confidence")
+        _eq(normal[i], on, f"{mode} view {r} normal")
+        rel = np.abs(depth[i] - g[f"depth_{r}"]) / g[f"depth_{r}"]
+        assert np.mean(rel <= 1e-3) >= E2E_MIN_FRACTION
+        hist_got = np.bincount(conf[i].astype(int).ravel(), minlength=5) / conf[i].size
+        hist_ref = np.bincount(g[f"confidence_{r}"].astype(int).ravel(), minlength=5) / conf[i].size
+        assert np.abs(hist_got - hist_ref).max() < CONF_HIST_TOL
+    od, oc = scene_d.oracle_ctx(int(s23["ref"]), list(s23["nbrs"]), int(s23["patch"]), mode).plane_sweep(planes, float(s23["thresh"]))
+    _eq(sd, od, f"{mode} sweep depth")
+    _eq(sc, oc, f"{mode} sweep confidence")
+    assert np.mean(sc == s23["confidence"]) > 0.995 and np.mean(sd == s23["depth_map"]) > 0.99

@@ -217,3 +217,23 @@ def test_large_patch_sizes_against_the_reference(scene_a, scene_d, mode):
     ctx = scene_d.oracle_ctx(int(g["ref"]), list(g["nbrs"]), int(g["patch"]), mode)
     d, conf = ctx.plane_sweep(g["depths"].astype(np.float32), float(g["thresh"]))
     assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cli_operating_points_against_the_reference(scene_d, mode):
+    """The operating points of the reference's CLI (run_reconstruction.py:131-136, :150-154), which the classes'
+    defaults reproduce: _patchmatch_cuda with patch 11, 3 iterations x 8 samples (g22, two views) and
+    _plane_sweep_torch with 64 planes, patch 5, 6 neighbours (g23) -- captured from the reference by
+    tests/golden/make_golden_r4.py, on identical RNG streams."""
+    g = load_golden("g22_patchmatch_cli")
+    for r in (int(x) for x in g["refs"]):
+        ctx = scene_d.oracle_ctx(r, list(g[f"srcs_{r}"]), int(g["patch"]), mode)
+        d, n, conf = ctx.patchmatch(int(g["iters"]), int(g["samples"]), scene_d.depth_min, scene_d.depth_max, int(g["seed"]), r)
+        _e2e_check(d, conf, g[f"depth_{r}"], g[f"confidence_{r}"], f"g22 view {r} ({mode})")
+        # normals of the pixels whose depth agrees: the same unit vectors
+        same = np.abs(d - g[f"depth_{r}"]) <= 1e-3 * g[f"depth_{r}"]
+        assert np.quantile(np.abs(n - g[f"normal_{r}"])[same].max(axis=-1), 0.99) < 1e-3
+    g = load_golden("g23_plane_sweep_cli")
+    ctx = scene_d.oracle_ctx(int(g["ref"]), list(g["nbrs"]), int(g["patch"]), mode)
+    d, conf = ctx.plane_sweep(g["depths"].astype(np.float32), float(g["thresh"]))
+    assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
