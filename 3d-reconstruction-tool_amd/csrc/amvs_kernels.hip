@@ -32,7 +32,12 @@ namespace amvs {
 #endif
 constexpr int min_waves(int K, int S)
 {
-    return ((S + 1) * K <= 40 && K <= 11 ? 4 : ((S + 1) * K <= 60 ? 3 : 2)) + AMVS_MIN_WAVES_BIAS;   // 13 x 13 and up: LDS allows three workgroups
+    // the smaller of what the registers allow (the window-sum stage holds (S + 1) K values) and what the LDS rings
+    // of the workgroups of a CU allow (13 x 13 and up: three workgroups, 17 x 17 and up: two)
+    const int by_regs = (S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2);
+    const int nl = S < AMVS_RING_LDS_SOURCES ? S : AMVS_RING_LDS_SOURCES;
+    const int by_lds = 163840 / (AMVS_WG_WAVES * (nl + 1) * K * AMVS_WAVE * 4 + 4096);
+    return (by_regs < by_lds ? by_regs : (by_lds < 1 ? 1 : by_lds)) + AMVS_MIN_WAVES_BIAS;
 }
 
 // MODE_T: MODE_PROP / MODE_REFINE are compiled as their own kernels (99 % of the launches: the mode
@@ -734,11 +739,13 @@ int step_waves_per_cu(int K, int S, bool u8, int wg_cap)
     case 11: AMVS_FOR_S(11, step_occupancy_ks, u8, wg_cap)
     case 13: AMVS_FOR_S(13, step_occupancy_ks, u8, wg_cap)
     case 15: AMVS_FOR_S(15, step_occupancy_ks, u8, wg_cap)
+    case 17: AMVS_FOR_S(17, step_occupancy_ks, u8, wg_cap)
+    case 19: AMVS_FOR_S(19, step_occupancy_ks, u8, wg_cap)
     default: return step_generic_waves_per_cu(K, S);
     }
 }
 
-bool patch_compiled(int K) { return K >= 3 && K <= 15 && (K & 1) == 1; }
+bool patch_compiled(int K) { return K >= 3 && K <= 19 && (K & 1) == 1; }
 bool patch_supported(int K) { return K >= 3 && K <= AMVS_MAX_PATCH && (K & 1) == 1; }
 bool step_pair_supported(int K, int S) { return patch_compiled(K) && S >= 2 && S <= AMVS_KMAX_SRC && step_pair_supported_ks(K, S); }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
@@ -756,6 +763,8 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
     case 11: AMVS_FOR_S(11, launch_step_ks, a, nblk, st)
     case 13: AMVS_FOR_S(13, launch_step_ks, a, nblk, st)
     case 15: AMVS_FOR_S(15, launch_step_ks, a, nblk, st)
+    case 17: AMVS_FOR_S(17, launch_step_ks, a, nblk, st)
+    case 19: AMVS_FOR_S(19, launch_step_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }
@@ -796,6 +805,14 @@ hipError_t launch_box_stats(int K, const float *images, long long img_stride, in
         break;
     case 15:
         hipLaunchKernelGGL((box_stats_kernel<15>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 17:
+        hipLaunchKernelGGL((box_stats_kernel<17>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 19:
+        hipLaunchKernelGGL((box_stats_kernel<19>), grid, blk, 0, st, images, img_stride, H, W, TH,
                            tiles_x, tiles_y, first_img, mean_out, var_out);
         break;
     default: return hipErrorInvalidValue;

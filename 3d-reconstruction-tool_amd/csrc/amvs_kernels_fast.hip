@@ -516,6 +516,8 @@ hipError_t launch_fast_stats(int K, const uint16_t *pairs_view, int H, int W, fl
     case 11: hipLaunchKernelGGL((fast_stats_kernel<11>), grid, blk, 0, st, pairs_view, H, W, out); break;
     case 13: hipLaunchKernelGGL((fast_stats_kernel<13>), grid, blk, 0, st, pairs_view, H, W, out); break;
     case 15: hipLaunchKernelGGL((fast_stats_kernel<15>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 17: hipLaunchKernelGGL((fast_stats_kernel<17>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 19: hipLaunchKernelGGL((fast_stats_kernel<19>), grid, blk, 0, st, pairs_view, H, W, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -615,6 +617,8 @@ int step_fast_waves_per_cu(int K, int S, int wg_cap)
     case 11: AMVS_FOR_S(11, step_fast_occupancy_ks, wg_cap)
     case 13: AMVS_FOR_S(13, step_fast_occupancy_ks, wg_cap)
     case 15: AMVS_FOR_S(15, step_fast_occupancy_ks, wg_cap)
+    case 17: AMVS_FOR_S(17, step_fast_occupancy_ks, wg_cap)
+    case 19: AMVS_FOR_S(19, step_fast_occupancy_ks, wg_cap)
     default: return step_generic_waves_per_cu(K, S);
     }
 }
@@ -633,6 +637,8 @@ hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
     case 11: AMVS_FOR_S(11, launch_step_fast_ks, a, nblk, st)
     case 13: AMVS_FOR_S(13, launch_step_fast_ks, a, nblk, st)
     case 15: AMVS_FOR_S(15, launch_step_fast_ks, a, nblk, st)
+    case 17: AMVS_FOR_S(17, launch_step_fast_ks, a, nblk, st)
+    case 19: AMVS_FOR_S(19, launch_step_fast_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

@@ -211,6 +211,8 @@ hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st)
     case 11: AMVS_FOR_S(11, launch_sweep_fast_ks, a, nblk, st)
     case 13: AMVS_FOR_S(13, launch_sweep_fast_ks, a, nblk, st)
     case 15: AMVS_FOR_S(15, launch_sweep_fast_ks, a, nblk, st)
+    case 17: AMVS_FOR_S(17, launch_sweep_fast_ks, a, nblk, st)
+    case 19: AMVS_FOR_S(19, launch_sweep_fast_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

@@ -58,8 +58,8 @@ typedef struct amvs_ctx amvs_ctx;
  * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
  * and (float)ln dmin formed in double by the host, as :268-271 does.           */
 typedef struct {
-    int32_t patch_size;       /* any odd size in 3..31 (mvs_patchmatch.py:45 takes any); 3, 5, ..., 15 run
-                                 kernels specialised at compile time, 17 ... 31 the run-time-k kernels
+    int32_t patch_size;       /* any odd size in 3..31 (mvs_patchmatch.py:45 takes any); 3, 5, ..., 19 run
+                                 kernels specialised at compile time, 21 ... 31 the run-time-k kernels
                                  (csrc/amvs_generic.hip: same results contract, classic schedule, slower)  */
     int32_t num_iterations;
     int32_t num_samples;
@@ -88,7 +88,7 @@ typedef struct {
 #define AMVS_SCHEDULE_VIEW_MAJOR  1
 #define AMVS_SCHEDULE_BAND_MAJOR  2
 #define AMVS_SCHEDULE_SPLIT       3
-#define AMVS_SCHEDULE_PAIRED      4   /* compiled patch sizes (3 .. 11), up to 4 sources, 8-bit images (the fast mode, and the
+#define AMVS_SCHEDULE_PAIRED      4   /* specialised patch sizes 3 .. 11, up to 4 sources, 8-bit images (the fast mode, and the
                                          exact mode on its packed maps): 2 x 2 strips per workgroup, vertically adjacent bands
                                          walk towards each other and exchange their boundary samples through LDS (K/2 halo
                                          rows per strip instead of K - 1); elsewhere it runs as view-major.

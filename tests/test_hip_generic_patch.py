@@ -1,8 +1,8 @@
 """Any odd patch size (round 4) against the CPU oracle, whose k is a run-time argument and which
 tests/test_oracle_modes_golden.py pins at k = 13, 15 against the reference's own outputs (g19, g20, g21).  The
 reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36, :325-341); the compiled kernels
-cover 3 ... 15 (13 and 15 since the end of round 4: 1.9x the run-time-k kernels' rate), every other odd size up to 31
-runs in the run-time-k kernels of csrc/amvs_generic.hip -- every test here visits both kinds.
+cover 3 ... 19 (13 ... 19 since the end of round 4: about twice the run-time-k kernels' rate), every other odd size up
+to 31 runs in the run-time-k kernels of csrc/amvs_generic.hip -- every test here visits both kinds.
 
 Bar: BIT-EXACT against the oracle in both arithmetic modes; the reference tolerances of tests/conftest.py against
 the goldens.
@@ -52,7 +52,7 @@ def test_box_stats_bit_exact(scene_a, k):
             _eq(var, ovar, f"var k{k}")
 
 
-@pytest.mark.parametrize("k", [13, 15, 17, 23, 31])
+@pytest.mark.parametrize("k", [13, 15, 17, 19, 23, 31])
 @pytest.mark.parametrize("srcs", [[1, 3, 0, 4], [3, 1], [0, 1, 4]])
 def test_eval_cost_bit_exact(eng_mode, scene_a, k, srcs):
     eng, mode = eng_mode
@@ -81,12 +81,12 @@ def test_confidence_bit_exact(eng_mode, scene_a):
     eng, mode = eng_mode
     g = load_golden("g07_confidence")
     ref, srcs = int(g["ref"]), list(g["srcs"])
-    for k in (13, 19):
+    for k in (13, 19, 21):
         got = eng.confidence(ref, srcs, k, g["depth"])
         _eq(got, scene_a.oracle_ctx(ref, srcs, k, mode).confidence(g["depth"]), f"{mode} confidence k{k}")
 
 
-@pytest.mark.parametrize("k", [13, 17])
+@pytest.mark.parametrize("k", [13, 17, 21])
 @pytest.mark.parametrize("off", [(1, 0), (0, 1), (-1, 0), (0, -1)])
 def test_propagate_step_bit_exact(eng_mode, scene_a, off, k):
     eng, mode = eng_mode
@@ -102,7 +102,7 @@ def test_propagate_step_bit_exact(eng_mode, scene_a, off, k):
     assert (got[0] != g["depth"]).mean() > 0.01
 
 
-@pytest.mark.parametrize("k", [15, 19])
+@pytest.mark.parametrize("k", [15, 19, 23])
 @pytest.mark.parametrize("it", [0, 2])
 def test_refine_step_bit_exact(eng_mode, scene_a, it, k):
     from oracle import oracle
@@ -164,19 +164,19 @@ def test_plane_sweep_k13_bit_exact_and_reference_golden(scene_d, mode):
         d, conf = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
         eng.set_sweep_tuning(tile_rows=5, planes_per_wave=3)              # several strips, several plane chunks
         d2, conf2 = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
-        d3, conf3 = eng.plane_sweep(ref, nbrs[:3], depths, 17, -0.2)       # the division form of the fast vote
+        d3, conf3 = eng.plane_sweep(ref, nbrs[:3], depths, 21, -0.2)       # the division form of the fast vote (run-time-k kernel)
     od, oc = scene_d.oracle_ctx(ref, nbrs, k, mode).plane_sweep(depths, float(g["thresh"]))
     _eq(d, od, f"{mode} depth")
     _eq(conf, oc, f"{mode} confidence")
     _eq(d2, od, f"{mode} depth (chunked)")
     _eq(conf2, oc, f"{mode} confidence (chunked)")
-    od3, oc3 = scene_d.oracle_ctx(ref, nbrs[:3], 17, mode).plane_sweep(depths, -0.2)
-    _eq(d3, od3, f"{mode} k17 depth")
-    _eq(conf3, oc3, f"{mode} k17 confidence")
+    od3, oc3 = scene_d.oracle_ctx(ref, nbrs[:3], 21, mode).plane_sweep(depths, -0.2)
+    _eq(d3, od3, f"{mode} k21 depth")
+    _eq(conf3, oc3, f"{mode} k21 confidence")
     assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
 
 
-@pytest.mark.parametrize("shape,k,S", [((33, 59), 13, 3), ((70, 117), 15, 3), ((35, 61), 17, 3), ((41, 200), 25, 2), ((20, 64), 31, 3)])
+@pytest.mark.parametrize("shape,k,S", [((33, 59), 13, 3), ((70, 117), 15, 3), ((35, 61), 17, 3), ((37, 66), 21, 3), ((41, 200), 25, 2), ((20, 64), 31, 3)])
 def test_ragged_shapes_and_float_images_bit_exact(shape, k, S):
     """Widths that are not multiples of the strip's output width (64 - 2 (k/2)), heights below the patch size, and
     rendered float images (not 8-bit exact: the exact arithmetic samples the float32 maps, U8 = false)."""
@@ -229,9 +229,9 @@ def test_largest_patch_with_six_sources(scene_d, mode):
     _eq(sc_, osc, f"{mode} k31 S6 sweep confidence")
 
 
-@pytest.mark.parametrize("patch", [13, 17])
+@pytest.mark.parametrize("patch", [13, 21])
 def test_classes_accept_any_odd_patch_size(scene_b, capsys, patch):
-    """PatchMatchMVS(patch_size=13 / 17) / DenseStereoReconstructor(patch_size=13 / 17) run end to end (the
+    """PatchMatchMVS(patch_size=13 / 21) / DenseStereoReconstructor(patch_size=13 / 21) run end to end (the
     reference's constructors take any patch size); even and oversized patches are refused with a message."""
     import amvs
     from amvs._lib import AmvsError
