@@ -16,6 +16,7 @@ sharded over the ranks (one process per GPU) and the 8 B/pixel maps all-gathered
 the fusion.  Every step is bit-identical to the host restatement below, which in turn is
 pinned by the reference's golden vectors (g11, g12, g16).
 """
+import threading
 import time
 from typing import Dict, List, Optional, Tuple
 
@@ -36,7 +37,7 @@ def _torch_cuda():
     return torch if torch.cuda.is_available() else None
 
 
-_DRAW_BUF = None            # (arange, scratch) of DenseStereoReconstructor._draw_without_replacement
+_DRAW_BUF = threading.local()     # .pair = (arange, scratch) of DenseStereoReconstructor._draw_without_replacement
 
 
 class DenseStereoReconstructor:
@@ -243,18 +244,17 @@ class DenseStereoReconstructor:
 
     def _draw_without_replacement(self, total: int, size: int) -> np.ndarray:
         """`np.random.choice(total, size, replace=False)` -- the reference's unseeded draw (dense_stereo.py:449-451) --
-        made in buffers the module keeps.  NumPy's legacy generator defines that call as `permutation(total)[:size]`
+        made in buffers the module keeps (one pair per thread).  NumPy's legacy generator defines that call as `permutation(total)[:size]`
         and `permutation(n)` as `arange(n)` shuffled in place, so shuffling a kept copy of `arange(total)` consumes the
         global generator identically and returns the same indices (checked against np.random.choice in
         tests/test_host_logic.py).  Why: the 4.8 MB array a fresh `choice` allocates is handed to the driver's
         host-to-device copy straight after it is written, and on this platform such a copy from a just-mapped host
         range takes 13-24 ms instead of 0.1 ms in every second call or so (measured); a buffer
         that is reused does not show it."""
-        global _DRAW_BUF                              # one pair of buffers per process
-        buf = _DRAW_BUF
+        buf = getattr(_DRAW_BUF, "pair", None)        # one pair of buffers per thread
         if buf is None or buf[0].size < total:
             cap = max(int(total), 1 << 20)
-            buf = _DRAW_BUF = (np.arange(cap, dtype=np.int64), np.empty(cap, np.int64))
+            buf = _DRAW_BUF.pair = (np.arange(cap, dtype=np.int64), np.empty(cap, np.int64))
         idx = buf[1][:total]
         np.copyto(idx, buf[0][:total])
         np.random.shuffle(idx)
