@@ -415,3 +415,42 @@ def test_native_rccl_entry_points_single_rank():
         eng.comm_destroy()
         with pytest.raises(amvs.AmvsError):
             eng.allgather_maps(d.data_ptr(), full.data_ptr(), hw)      # no communicator any more
+
+
+def test_reused_context_gives_a_fresh_objects_results(capsys):
+    """Round 4: both classes keep their device context between reconstruct calls on the same problem size and upload
+    the next call's views into it.  A second call with OTHER images and poses of the same size must return exactly
+    what a fresh object returns for them (no state of the first scene survives: reference statistics, packed maps,
+    resident clouds, continuation state), and a call with another size must get a new context."""
+    import amvs as amvs_mod
+    from amvs.synthetic import make_scene
+    a = make_scene(5, 96, 128, seed=3)
+    b = make_scene(5, 96, 128, seed=9, arc_step_deg=14.0)
+    c = make_scene(5, 80, 112, seed=4)
+    cam = amvs_mod.Camera(K=a.camera.K.copy(), dist=np.zeros(5))
+    cam_c = amvs_mod.Camera(K=c.camera.K.copy(), dist=np.zeros(5))
+
+    def mvs(camera):
+        return amvs_mod.PatchMatchMVS(camera, scale=1.0, patch_size=7, num_iterations=2, num_samples=3, min_views=2, seed=5,
+                                      device_prep=True)
+
+    def stereo(camera):
+        return amvs_mod.DenseStereoReconstructor(camera, scale=1.0, num_depths=24, min_views=2, device_prep=True)
+    for make in (mvs, stereo):
+        kept = make(cam)
+        kept.reconstruct(a.images(), a.poses)
+        first_engine = kept._engine
+        got = kept.reconstruct(b.images(), b.poses)
+        assert kept._engine is first_engine                      # reused
+        want = make(cam).reconstruct(b.images(), b.poses)
+        assert len(want[0]) > 100
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        again = kept.reconstruct(a.images(), a.poses)
+        fresh_a = make(cam).reconstruct(a.images(), a.poses)
+        assert np.array_equal(again[0], fresh_a[0]) and np.array_equal(again[1], fresh_a[1])
+        kept.camera, kept.K_scaled = cam_c, cam_c.K.copy()       # another size (and intrinsics): a new context
+        other = kept.reconstruct(c.images(), c.poses)
+        assert kept._engine is not first_engine
+        want_c = make(cam_c).reconstruct(c.images(), c.poses)
+        assert np.array_equal(other[0], want_c[0]) and np.array_equal(other[1], want_c[1])
+    capsys.readouterr()
