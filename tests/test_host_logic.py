@@ -356,3 +356,38 @@ def test_stereo_subsample_draw_equals_numpy_choice():
         got = ds._draw_without_replacement(total, size)
         after_got = np.random.rand()
         assert got.dtype == want.dtype and np.array_equal(got, want) and after_got == after_want
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The driver-shaped line of the final build (profiles/r04_logs/bench_default_line.json, written by
+    `python bench.py --steps 20 --warmup 5` on an MI355X) carries every field the bench contract names, the figures
+    agree with each other, and every replayed traffic figure names its profile."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r04_logs", "bench_default_line.json")
+    lines = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["higher_is_better"] is True and r["vs_baseline"] is None and r["dtype"] == "f32"
+    assert "workload" in r["config"] and "model" not in r["config"] and "config 3" in r["config"]["workload"]
+    assert r["data"].startswith("synthetic")
+    # value = pixel-hypotheses per step / time per step
+    assert abs(r["value"] - r["config"]["pixel_hypotheses_per_step"] / r["ms_per_step"] / 1e3) < 0.01 * r["value"]
+    records = [("main", r), ("planesweep", r["planesweep"]), ("exact.patchmatch", r["exact"]["patchmatch"]),
+               ("exact.planesweep", r["exact"]["planesweep"]), ("cli_defaults", r["cli_defaults"])]
+    for name, rec in records:
+        roof = rec["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in roof, (name, key)
+        assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["unit"] == "GB/s"
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 0.01 * roof["achieved"]
+        assert roof["traffic"] is not None and roof["traffic_source"].startswith("profiles/r04_"), name
+        assert roof["traffic"] < 3 * roof["algorithmic_bytes_per_launch"]
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["unit"] == r["unit"] and "sample" in cpu
+    cli = r["cli_defaults"]
+    assert len(cli["timed_calls_s"]) == 5 and min(cli["timed_calls_s"]) <= cli["end_to_end_s"] <= max(cli["timed_calls_s"])
+    assert len(cli["stereo"]["timed_calls_s"]) == 5
