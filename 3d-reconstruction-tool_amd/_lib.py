@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("AMVS_LIB") or os.path.join(_HERE, "libamvs.so")
 AMVS_MAX_SRC = 6
 MODES = {"default": 0, "exact": 1, "fast": 2}
 SCHEDULES = {"auto": 0, "view-major": 1, "band-major": 2, "split": 3, "paired": 4}
-SUPPORTED_PATCH_SIZES = tuple(range(3, 32, 2))        # compiled: 3 ... 19; the others run the run-time-k kernels
+SUPPORTED_PATCH_SIZES = tuple(range(3, 32, 2))        # compiled: 3 ... 29; 31 runs the run-time-k kernels
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int)

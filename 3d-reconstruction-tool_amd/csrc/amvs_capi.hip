@@ -1104,7 +1104,7 @@ static int patchmatch_core(amvs_ctx *c, int n_ref, const int *ref_ids, const int
     if (p->schedule == AMVS_SCHEDULE_SPLIT && !fast)
         return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists in fast mode only");
     if (p->schedule == AMVS_SCHEDULE_SPLIT && !amvs::patch_compiled(p->patch_size))
-        return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists for the compiled patch sizes (3 ... 19) only");
+        return fail(c, AMVS_EUNSUPPORTED, "the split schedule exists for the compiled patch sizes (3 ... 29) only");
     // Continuation: iterations first_iteration .. of a sweep whose earlier iterations a previous call ran
     // on the same batch; the state maps stay in the context between the calls.
     if (p->first_iteration < 0) return fail(c, AMVS_EINVAL, "negative first_iteration");

@@ -122,18 +122,21 @@ template <int S> struct HSum { static constexpr int NV4 = S <= 4 ? 3 : 5; };
 #ifndef AMVS_RING_LDS_SOURCES
 #define AMVS_RING_LDS_SOURCES 2
 #endif
-template <int S> struct Ring {
-    static constexpr int NL = AMVS_RING_LDS_SOURCES < S ? AMVS_RING_LDS_SOURCES : S;   // sources in LDS
+// (21 x 21 and up: ONE source in LDS -- the rings of a four-wave workgroup must stay below the 64 KB a workgroup
+// may take; the registers hold the others, at two waves per SIMD)
+constexpr int ring_lds_sources(int K) { return K <= 19 ? AMVS_RING_LDS_SOURCES : 1; }
+template <int K, int S> struct Ring {
+    static constexpr int NL = ring_lds_sources(K) < S ? ring_lds_sources(K) : S;       // sources in LDS
     static constexpr int NR = S - NL > 0 ? S - NL : 1;                                  // register rings (>=1 for the type)
     static constexpr bool REF_IN_LDS = NL > 0;
 };
 
 template <int K, int S>
-AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], float (&ring_v)[Ring<S>::NR][K],
+AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], float (&ring_v)[Ring<K, S>::NR][K],
                         float rv, const float (&v)[S])
 {
-    constexpr int NL = Ring<S>::NL;
-    if (Ring<S>::REF_IN_LDS) {
+    constexpr int NL = Ring<K, S>::NL;
+    if (Ring<K, S>::REF_IN_LDS) {
         lring[wslot * AMVS_WAVE + lane] = rv;
 #pragma unroll
         for (int s = 0; s < NL; ++s) lring[((s + 1) * K + wslot) * AMVS_WAVE + lane] = v[s];
@@ -161,11 +164,11 @@ AMVS_DEV void ring_push(float *lring, int lane, int wslot, float (&ring_r)[K], f
 // bound by its instruction count alone, the plane sweep is.)
 template <int K, int S, bool REV = false, bool REFSUMS = true>
 AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[K],
-                          const float (&ring_v)[Ring<S>::NR][K], float4 *hbuf, int lane,
+                          const float (&ring_v)[Ring<K, S>::NR][K], float4 *hbuf, int lane,
                           float (&bv)[S], float (&bvv)[S], float (&brv)[S], float &br, float &brr)
 {
     constexpr int NV4 = HSum<S>::NV4;
-    constexpr int NL = Ring<S>::NL;
+    constexpr int NL = Ring<K, S>::NL;
     float cs[NV4 * 4];
 #pragma unroll
     for (int i = 0; i < NV4 * 4; ++i) cs[i] = 0.0f;
@@ -176,7 +179,7 @@ AMVS_DEV void window_sums(const float *lring, int oldest, const float (&ring_r)[
     for (int i = 0; i < K; ++i) {
         const int j = REV ? K - 1 - i : i;              // window row i (top -> bottom) = ring age j
         slot[i] = oldest + j >= K ? oldest + j - K : oldest + j;
-        rr[i] = Ring<S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[j];
+        rr[i] = Ring<K, S>::REF_IN_LDS ? lring[slot[i] * AMVS_WAVE + lane] : ring_r[j];
     }
     // window sums of the reference image itself (r, r*r): the statistics mean1 / var1 of
     // mvs_patchmatch.py:403,406, recomputed from the ring (same order as box_stats_kernel, so the

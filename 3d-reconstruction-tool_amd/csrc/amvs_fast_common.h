@@ -24,8 +24,10 @@ namespace amvs {
 // gathers (2 cycles per distinct 128-byte line, tools/gather_rate.hip), not by latency, so the extra
 // waves only add L2 misses.
 
-template <int S> struct FRing {
-    static constexpr int NL = AMVS_FAST_RING_LDS < S ? AMVS_FAST_RING_LDS : S;
+// (21 x 21 and up: two sources in LDS, see ring_lds_sources in amvs_exact_common.h)
+constexpr int fast_ring_lds(int K) { return K <= 19 ? AMVS_FAST_RING_LDS : 2; }
+template <int K, int S> struct FRing {
+    static constexpr int NL = fast_ring_lds(K) < S ? fast_ring_lds(K) : S;
     static constexpr int NR = S - NL > 0 ? S - NL : 1;
 };
 
@@ -222,9 +224,9 @@ AMVS_DEV unsigned fast_sample_sources_checked(JobCP job, const FastConsts &fc, c
 }
 
 template <int K, int S>
-AMVS_DEV void fring_push(float *lring, int lane, int wslot, float (&ring_v)[FRing<S>::NR][K], const float (&v)[S])
+AMVS_DEV void fring_push(float *lring, int lane, int wslot, float (&ring_v)[FRing<K, S>::NR][K], const float (&v)[S])
 {
-    constexpr int NL = FRing<S>::NL;
+    constexpr int NL = FRing<K, S>::NL;
 #pragma unroll
     for (int s = 0; s < NL; ++s) lring[(s * K + wslot) * AMVS_WAVE + lane] = v[s];
 #pragma unroll
@@ -243,10 +245,10 @@ AMVS_DEV void fring_push(float *lring, int lane, int wslot, float (&ring_v)[FRin
 // order of the same values.
 template <int K, int S, bool REV = false>
 AMVS_DEV void window_sums_fast(const float *lring, int oldest, const float (&rr_in)[K],
-                               const float (&ring_v)[FRing<S>::NR][K], int lane,
+                               const float (&ring_v)[FRing<K, S>::NR][K], int lane,
                                float (&bv)[S], float (&bvv)[S], float (&brv)[S])
 {
-    constexpr int NL = FRing<S>::NL;
+    constexpr int NL = FRing<K, S>::NL;
     int slot[K];
     float rr[K];
 #pragma unroll

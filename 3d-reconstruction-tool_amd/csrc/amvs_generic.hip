@@ -1,7 +1,7 @@
 // amvs_generic.hip -- the sweep step, the plane sweep and the reference statistics for ANY odd patch size
 // up to AMVS_MAX_PATCH (the reference takes any patch_size: mvs_patchmatch.py:45, box kernel built from it
 // at :396-397; dense_stereo.py:36, :325-341).  The kernels of amvs_kernels.hip / amvs_kernels_fast.hip /
-// amvs_sweep_fast.hip are compiled for k = 3, 5, ..., 19 (rings in registers, unrolled window sums); every
+// amvs_sweep_fast.hip are compiled for k = 3, 5, ..., 29 (rings in registers, unrolled window sums); every
 // other odd k runs here, with the patch size a launch argument:
 //   * the same strip shape (a wave owns 64 columns and walks its rows top to bottom, 64 - 2 (k/2) output
 //     columns), one wave per workgroup;

@@ -53,7 +53,9 @@ AMVS_DEV void strip_of(const StepArgs &a, int t, int &job_id, int &ty, int &tx)
 
 // per-row validity bits of the last K/2+1 rows packed into one (or two) registers
 template <int K, int S> struct Hist {
-    typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t, unsigned long long>::type T;
+    // (more than 64 bits from 21 x 21 with 6 sources on: a 128-bit integer, two more shifts per row)
+    typedef typename std::conditional<(S * (K / 2 + 1) <= 32), uint32_t,
+                                      typename std::conditional<(S * (K / 2 + 1) <= 64), unsigned long long, unsigned __int128>::type>::type T;
 };
 
 // Depth state maps carry, in the sign bit, the normal buffer that holds the pixel's current normal

@@ -119,7 +119,7 @@ struct SweepArgs : StepArgsBase {
 };
 
 bool patch_supported(int K);          // any odd patch size in 3 .. AMVS_MAX_PATCH
-bool patch_compiled(int K);           // ... with kernels specialised at compile time (3, 5, ..., 19); the others run
+bool patch_compiled(int K);           // ... with kernels specialised at compile time (3, 5, ..., 29); the others run
                                       // the run-time-k kernels of amvs_generic.hip
 // amvs_generic.hip: sweep step / plane sweep / statistics with the patch size as a launch argument (both
 // arithmetic modes, classic schedule); launch_step / launch_sweep / launch_box_stats / launch_fast_stats forward

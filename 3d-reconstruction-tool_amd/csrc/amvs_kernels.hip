@@ -35,7 +35,7 @@ constexpr int min_waves(int K, int S)
     // the smaller of what the registers allow (the window-sum stage holds (S + 1) K values) and what the LDS rings
     // of the workgroups of a CU allow (13 x 13 and up: three workgroups, 17 x 17 and up: two)
     const int by_regs = (S + 1) * K <= 40 ? 4 : ((S + 1) * K <= 60 ? 3 : 2);
-    const int nl = S < AMVS_RING_LDS_SOURCES ? S : AMVS_RING_LDS_SOURCES;
+    const int nl = S < ring_lds_sources(K) ? S : ring_lds_sources(K);
     const int by_lds = 163840 / (AMVS_WG_WAVES * (nl + 1) * K * AMVS_WAVE * 4 + 4096);
     return (by_regs < by_lds ? by_regs : (by_lds < 1 ? 1 : by_lds)) + AMVS_MIN_WAVES_BIAS;
 }
@@ -60,18 +60,18 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
 #else
     float4 *hbuf = nullptr;
 #endif
-    __shared__ float lring_all[WGW * (Ring<S>::NL + 1) * K * AMVS_WAVE];
+    __shared__ float lring_all[WGW * (Ring<K, S>::NL + 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;                    // refinement winners waiting for their normal
     __shared__ uint32_t nq_all[WGW * NQ];
     // paired bands: the partner's rows of the LDS-resident sources are read from the partner's ring itself (see
     // pm_step_fast_kernel); exchange rows only for the XS sources with register rings
-    constexpr int XS = S - Ring<S>::NL > 0 ? S - Ring<S>::NL : 0;
+    constexpr int XS = S - Ring<K, S>::NL > 0 ? S - Ring<K, S>::NL : 0;
     constexpr int XW = HALF * XS * AMVS_WAVE;            // floats of a wave's exchange rows [row][register source][lane]
     __shared__ float xbuf_all[PAIR && XS > 0 ? WGW * XW : 1];
 
     const int lane = threadIdx.x & (AMVS_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / AMVS_WAVE);
-    float *lring = lring_all + wv * ((Ring<S>::NL + 1) * K * AMVS_WAVE);
+    float *lring = lring_all + wv * ((Ring<K, S>::NL + 1) * K * AMVS_WAVE);
     uint32_t *nq = nq_all + wv * NQ;
     int q_head = 0, q_tail = 0;                          // wave-uniform; at most 63 + 58 entries queued
     window_sums_init<K, S>(hbuf, lane);
@@ -141,19 +141,19 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
     const int y_start = up ? y0 + th_w + HALF - 1 : y0 - HALF, dy = up ? -1 : 1;
     float *xmine = PAIR ? xbuf_all + wv * XW : nullptr;
     const float *xpartner = PAIR ? xbuf_all + (wv ^ AMVS_PAIR_COLS) * XW : nullptr;
-    const float *lring_p = PAIR ? lring_all + (wv ^ AMVS_PAIR_COLS) * ((Ring<S>::NL + 1) * K * AMVS_WAVE) : nullptr;
+    const float *lring_p = PAIR ? lring_all + (wv ^ AMVS_PAIR_COLS) * ((Ring<K, S>::NL + 1) * K * AMVS_WAVE) : nullptr;
     int pslot = 0;                      // ring slot of the partner's own row next to the boundary
     if (PAIR && paired) pslot = (min(a.TH, H - (ty ^ 1) * a.TH) + HALF - 1) % K;
 
     float ring_r[K];
-    float ring_v[Ring<S>::NR][K];
+    float ring_v[Ring<K, S>::NR][K];
     typename Hist<K, S>::T hist_ok = 0;    // S validity bits per row, newest row in the top bits
     uint32_t hist_h0[HALF + 1];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         ring_r[i] = 0.0f;
 #pragma unroll
-        for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
+        for (int s = 0; s < Ring<K, S>::NR; ++s) ring_v[s][i] = 0.0f;
     }
 #pragma unroll
     for (int i = 0; i <= HALF; ++i) hist_h0[i] = 0u;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
         if (PAIR && !own) {
             // a row of the partner band: its samples, taken at its own candidates, from LDS (the partner
             // wrote them walking towards the boundary: the row next to it last)
-            constexpr int NLS = Ring<S>::NL;
+            constexpr int NLS = Ring<K, S>::NL;
             const float *xp = xpartner + (HALF - 1 - (loc - n_own)) * (XS * AMVS_WAVE);
 #pragma unroll
             for (int s = 0; s < S; ++s)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), mi
                 if (XS > 0 && paired && loc >= n_own - HALF) {  // the last K/2 own rows: for the partner
                     float *xm = xmine + (loc - (n_own - HALF)) * (XS * AMVS_WAVE);
 #pragma unroll
-                    for (int s = Ring<S>::NL; s < S; ++s) xm[(s - Ring<S>::NL) * AMVS_WAVE + lane] = v[s];
+                    for (int s = Ring<K, S>::NL; s < S; ++s) xm[(s - Ring<K, S>::NL) * AMVS_WAVE + lane] = v[s];
                 }
             }
         }
@@ -741,11 +741,16 @@ int step_waves_per_cu(int K, int S, bool u8, int wg_cap)
     case 15: AMVS_FOR_S(15, step_occupancy_ks, u8, wg_cap)
     case 17: AMVS_FOR_S(17, step_occupancy_ks, u8, wg_cap)
     case 19: AMVS_FOR_S(19, step_occupancy_ks, u8, wg_cap)
+    case 21: AMVS_FOR_S(21, step_occupancy_ks, u8, wg_cap)
+    case 23: AMVS_FOR_S(23, step_occupancy_ks, u8, wg_cap)
+    case 25: AMVS_FOR_S(25, step_occupancy_ks, u8, wg_cap)
+    case 27: AMVS_FOR_S(27, step_occupancy_ks, u8, wg_cap)
+    case 29: AMVS_FOR_S(29, step_occupancy_ks, u8, wg_cap)
     default: return step_generic_waves_per_cu(K, S);
     }
 }
 
-bool patch_compiled(int K) { return K >= 3 && K <= 19 && (K & 1) == 1; }
+bool patch_compiled(int K) { return K >= 3 && K <= 29 && (K & 1) == 1; }
 bool patch_supported(int K) { return K >= 3 && K <= AMVS_MAX_PATCH && (K & 1) == 1; }
 bool step_pair_supported(int K, int S) { return patch_compiled(K) && S >= 2 && S <= AMVS_KMAX_SRC && step_pair_supported_ks(K, S); }
 int strip_out_width(int K) { return AMVS_WAVE - 2 * (K / 2); }
@@ -765,6 +770,11 @@ hipError_t launch_step(int K, int S, const StepArgs &a, hipStream_t st)
     case 15: AMVS_FOR_S(15, launch_step_ks, a, nblk, st)
     case 17: AMVS_FOR_S(17, launch_step_ks, a, nblk, st)
     case 19: AMVS_FOR_S(19, launch_step_ks, a, nblk, st)
+    case 21: AMVS_FOR_S(21, launch_step_ks, a, nblk, st)
+    case 23: AMVS_FOR_S(23, launch_step_ks, a, nblk, st)
+    case 25: AMVS_FOR_S(25, launch_step_ks, a, nblk, st)
+    case 27: AMVS_FOR_S(27, launch_step_ks, a, nblk, st)
+    case 29: AMVS_FOR_S(29, launch_step_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }
@@ -813,6 +823,26 @@ hipError_t launch_box_stats(int K, const float *images, long long img_stride, in
         break;
     case 19:
         hipLaunchKernelGGL((box_stats_kernel<19>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 21:
+        hipLaunchKernelGGL((box_stats_kernel<21>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 23:
+        hipLaunchKernelGGL((box_stats_kernel<23>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 25:
+        hipLaunchKernelGGL((box_stats_kernel<25>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 27:
+        hipLaunchKernelGGL((box_stats_kernel<27>), grid, blk, 0, st, images, img_stride, H, W, TH,
+                           tiles_x, tiles_y, first_img, mean_out, var_out);
+        break;
+    case 29:
+        hipLaunchKernelGGL((box_stats_kernel<29>), grid, blk, 0, st, images, img_stride, H, W, TH,
                            tiles_x, tiles_y, first_img, mean_out, var_out);
         break;
     default: return hipErrorInvalidValue;

@@ -27,11 +27,11 @@ namespace amvs {
 #define AMVS_REF_PAIR_IDX(i) AMVS_IDX_LOHI((i), -((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER), (long long)(H + 2 * AMVS_PAIR_BORDER) * (W + 2 * AMVS_PAIR_BORDER) - ((long long)AMVS_PAIR_BORDER * (W + 2 * AMVS_PAIR_BORDER) + AMVS_PAIR_BORDER))
 
 template <int K, int S> struct StepLds {
-    static constexpr unsigned PER_WAVE = (FRing<S>::NL > 0 ? FRing<S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 4u;
+    static constexpr unsigned PER_WAVE = (FRing<K, S>::NL > 0 ? FRing<K, S>::NL : 1) * K * AMVS_WAVE * 4u + 2u * AMVS_WAVE * 4u;
     static constexpr unsigned STATIC = AMVS_WG_WAVES * PER_WAVE;
     // paired bands: the exchange rows of a wave -- only the sources whose ring lives in registers; the others are
     // read straight from the partner's LDS ring
-    static constexpr unsigned XBUF = (K / 2) * (S - FRing<S>::NL > 0 ? S - FRing<S>::NL : 0) * AMVS_WAVE * 4u;
+    static constexpr unsigned XBUF = (K / 2) * (S - FRing<K, S>::NL > 0 ? S - FRing<K, S>::NL : 0) * AMVS_WAVE * 4u;
     static unsigned extra(int wg_cap, bool pair = false)
     {
         // wg_cap counts workgroups of AMVS_WG_WAVES waves; a paired workgroup of PAIR_WAVES waves takes
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));      // 1 / (k^2 * 255)
     constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));    // 1 / (k^2 * 255^2)
-    constexpr int NL = FRing<S>::NL;
+    constexpr int NL = FRing<K, S>::NL;
     __shared__ float lring_all[WGW * (NL > 0 ? NL : 1) * K * AMVS_WAVE];
     constexpr int NQ = 2 * AMVS_WAVE;
     __shared__ uint32_t nq_all[WGW * NQ];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
     if (PAIR && paired) pslot = (min(a.TH, H - (ty ^ 1) * a.TH) + HALF - 1) % K;
 
     uint32_t rb[RefBytes<K>::NB];
-    float ring_v[FRing<S>::NR][K];
+    float ring_v[FRing<K, S>::NR][K];
     typename Hist<K, S>::T hist_ok = 0;
     uint32_t hist_h0[HALF + 1];
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(AMVS_WAVE * (PAIR ? PAIR_WAVES : AMVS_WG_WAVES), fa
 #pragma unroll
     for (int i = 0; i < K; ++i)
 #pragma unroll
-        for (int s = 0; s < FRing<S>::NR; ++s) ring_v[s][i] = 0.0f;
+        for (int s = 0; s < FRing<K, S>::NR; ++s) ring_v[s][i] = 0.0f;
 #pragma unroll
     for (int i = 0; i <= HALF; ++i) hist_h0[i] = 0u;
     int wslot = 0;
@@ -518,6 +518,11 @@ hipError_t launch_fast_stats(int K, const uint16_t *pairs_view, int H, int W, fl
     case 15: hipLaunchKernelGGL((fast_stats_kernel<15>), grid, blk, 0, st, pairs_view, H, W, out); break;
     case 17: hipLaunchKernelGGL((fast_stats_kernel<17>), grid, blk, 0, st, pairs_view, H, W, out); break;
     case 19: hipLaunchKernelGGL((fast_stats_kernel<19>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 21: hipLaunchKernelGGL((fast_stats_kernel<21>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 23: hipLaunchKernelGGL((fast_stats_kernel<23>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 25: hipLaunchKernelGGL((fast_stats_kernel<25>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 27: hipLaunchKernelGGL((fast_stats_kernel<27>), grid, blk, 0, st, pairs_view, H, W, out); break;
+    case 29: hipLaunchKernelGGL((fast_stats_kernel<29>), grid, blk, 0, st, pairs_view, H, W, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -619,6 +624,11 @@ int step_fast_waves_per_cu(int K, int S, int wg_cap)
     case 15: AMVS_FOR_S(15, step_fast_occupancy_ks, wg_cap)
     case 17: AMVS_FOR_S(17, step_fast_occupancy_ks, wg_cap)
     case 19: AMVS_FOR_S(19, step_fast_occupancy_ks, wg_cap)
+    case 21: AMVS_FOR_S(21, step_fast_occupancy_ks, wg_cap)
+    case 23: AMVS_FOR_S(23, step_fast_occupancy_ks, wg_cap)
+    case 25: AMVS_FOR_S(25, step_fast_occupancy_ks, wg_cap)
+    case 27: AMVS_FOR_S(27, step_fast_occupancy_ks, wg_cap)
+    case 29: AMVS_FOR_S(29, step_fast_occupancy_ks, wg_cap)
     default: return step_generic_waves_per_cu(K, S);
     }
 }
@@ -639,6 +649,11 @@ hipError_t launch_step_fast(int K, int S, const StepArgs &a, hipStream_t st)
     case 15: AMVS_FOR_S(15, launch_step_fast_ks, a, nblk, st)
     case 17: AMVS_FOR_S(17, launch_step_fast_ks, a, nblk, st)
     case 19: AMVS_FOR_S(19, launch_step_fast_ks, a, nblk, st)
+    case 21: AMVS_FOR_S(21, launch_step_fast_ks, a, nblk, st)
+    case 23: AMVS_FOR_S(23, launch_step_fast_ks, a, nblk, st)
+    case 25: AMVS_FOR_S(25, launch_step_fast_ks, a, nblk, st)
+    case 27: AMVS_FOR_S(27, launch_step_fast_ks, a, nblk, st)
+    case 29: AMVS_FOR_S(29, launch_step_fast_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
 #else
     float4 *hbuf = nullptr;
 #endif
-    __shared__ float lring[(Ring<S>::NL + 1) * K * AMVS_WAVE];
+    __shared__ float lring[(Ring<K, S>::NL + 1) * K * AMVS_WAVE];
 
     const int lane = threadIdx.x;
     window_sums_init<K, S>(hbuf, lane);
@@ -164,13 +164,13 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_kernel(const SweepArgs 
     for (int d = d_begin; d < d_end; ++d) {
         const float depth = a.depths[AMVS_IDX(d, a.D)];
         float ring_r[K];
-        float ring_v[Ring<S>::NR][K];
+        float ring_v[Ring<K, S>::NR][K];
         typename Hist<K, S>::T hist_ok = 0;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             ring_r[i] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < Ring<S>::NR; ++s) ring_v[s][i] = 0.0f;
+            for (int s = 0; s < Ring<K, S>::NR; ++s) ring_v[s][i] = 0.0f;
         }
         int wslot = 0;
 
@@ -323,6 +323,11 @@ hipError_t launch_sweep(int K, int S, const SweepArgs &a, hipStream_t st)
     case 15: AMVS_FOR_S(15, launch_sweep_ks, a, nblk, st)
     case 17: AMVS_FOR_S(17, launch_sweep_ks, a, nblk, st)
     case 19: AMVS_FOR_S(19, launch_sweep_ks, a, nblk, st)
+    case 21: AMVS_FOR_S(21, launch_sweep_ks, a, nblk, st)
+    case 23: AMVS_FOR_S(23, launch_sweep_ks, a, nblk, st)
+    case 25: AMVS_FOR_S(25, launch_sweep_ks, a, nblk, st)
+    case 27: AMVS_FOR_S(27, launch_sweep_ks, a, nblk, st)
+    case 29: AMVS_FOR_S(29, launch_sweep_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

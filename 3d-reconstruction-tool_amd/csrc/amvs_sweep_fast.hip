@@ -19,7 +19,7 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
     constexpr int OUTW = AMVS_WAVE - 2 * HALF;
     constexpr float C1 = (float)(1.0 / ((double)(K * K) * 255.0));
     constexpr float C2 = (float)(1.0 / ((double)(K * K) * 65025.0));
-    constexpr int NL = FRing<S>::NL;
+    constexpr int NL = FRing<K, S>::NL;
     __shared__ uint16_t best[AMVS_SWEEP_MAX_TH][AMVS_WAVE];
     __shared__ float lring[(NL > 0 ? NL : 1) * K * AMVS_WAVE];
 
@@ -84,14 +84,14 @@ __global__ __launch_bounds__(AMVS_WAVE) void plane_sweep_fast_kernel(const Sweep
         }
         const bool lean_strip = __all(lean_ok);
         uint32_t rb[RefBytes<K>::NB];
-        float ring_v[FRing<S>::NR][K];
+        float ring_v[FRing<K, S>::NR][K];
         typename Hist<K, S>::T hist_ok = 0;
 #pragma unroll
         for (int i = 0; i < RefBytes<K>::NB; ++i) rb[i] = 0u;
 #pragma unroll
         for (int i = 0; i < K; ++i)
 #pragma unroll
-            for (int s = 0; s < FRing<S>::NR; ++s) ring_v[s][i] = 0.0f;
+            for (int s = 0; s < FRing<K, S>::NR; ++s) ring_v[s][i] = 0.0f;
         int wslot = 0;
 
         for (int r = 0; r < rows; ++r) {
@@ -213,6 +213,11 @@ hipError_t launch_sweep_fast(int K, int S, const SweepArgs &a, hipStream_t st)
     case 15: AMVS_FOR_S(15, launch_sweep_fast_ks, a, nblk, st)
     case 17: AMVS_FOR_S(17, launch_sweep_fast_ks, a, nblk, st)
     case 19: AMVS_FOR_S(19, launch_sweep_fast_ks, a, nblk, st)
+    case 21: AMVS_FOR_S(21, launch_sweep_fast_ks, a, nblk, st)
+    case 23: AMVS_FOR_S(23, launch_sweep_fast_ks, a, nblk, st)
+    case 25: AMVS_FOR_S(25, launch_sweep_fast_ks, a, nblk, st)
+    case 27: AMVS_FOR_S(27, launch_sweep_fast_ks, a, nblk, st)
+    case 29: AMVS_FOR_S(29, launch_sweep_fast_ks, a, nblk, st)
     default: return hipErrorInvalidValue;
     }
 }

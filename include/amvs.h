@@ -58,8 +58,8 @@ typedef struct amvs_ctx amvs_ctx;
  * (:141-165).  log_depth_scale / log_depth_min are (float)(ln dmax - ln dmin)
  * and (float)ln dmin formed in double by the host, as :268-271 does.           */
 typedef struct {
-    int32_t patch_size;       /* any odd size in 3..31 (mvs_patchmatch.py:45 takes any); 3, 5, ..., 19 run
-                                 kernels specialised at compile time, 21 ... 31 the run-time-k kernels
+    int32_t patch_size;       /* any odd size in 3..31 (mvs_patchmatch.py:45 takes any); 3, 5, ..., 29 run
+                                 kernels specialised at compile time, 31 the run-time-k kernels
                                  (csrc/amvs_generic.hip: same results contract, classic schedule, slower)  */
     int32_t num_iterations;
     int32_t num_samples;

@@ -1,8 +1,8 @@
 """Any odd patch size (round 4) against the CPU oracle, whose k is a run-time argument and which
 tests/test_oracle_modes_golden.py pins at k = 13, 15 against the reference's own outputs (g19, g20, g21).  The
 reference takes any patch_size (mvs_patchmatch.py:45, :396-397; dense_stereo.py:36, :325-341); the compiled kernels
-cover 3 ... 19 (13 ... 19 since the end of round 4: about twice the run-time-k kernels' rate), every other odd size up
-to 31 runs in the run-time-k kernels of csrc/amvs_generic.hip -- every test here visits both kinds.
+cover 3 ... 29 (13 ... 29 since the end of round 4: two to four times the run-time-k kernels' rate); 31, the largest
+size, runs in the run-time-k kernels of csrc/amvs_generic.hip -- every test here visits both kinds.
 
 Bar: BIT-EXACT against the oracle in both arithmetic modes; the reference tolerances of tests/conftest.py against
 the goldens.
@@ -81,12 +81,12 @@ def test_confidence_bit_exact(eng_mode, scene_a):
     eng, mode = eng_mode
     g = load_golden("g07_confidence")
     ref, srcs = int(g["ref"]), list(g["srcs"])
-    for k in (13, 19, 21):
+    for k in (13, 19, 21, 31):
         got = eng.confidence(ref, srcs, k, g["depth"])
         _eq(got, scene_a.oracle_ctx(ref, srcs, k, mode).confidence(g["depth"]), f"{mode} confidence k{k}")
 
 
-@pytest.mark.parametrize("k", [13, 17, 21])
+@pytest.mark.parametrize("k", [13, 17, 21, 27, 31])
 @pytest.mark.parametrize("off", [(1, 0), (0, 1), (-1, 0), (0, -1)])
 def test_propagate_step_bit_exact(eng_mode, scene_a, off, k):
     eng, mode = eng_mode
@@ -102,7 +102,7 @@ def test_propagate_step_bit_exact(eng_mode, scene_a, off, k):
     assert (got[0] != g["depth"]).mean() > 0.01
 
 
-@pytest.mark.parametrize("k", [15, 19, 23])
+@pytest.mark.parametrize("k", [15, 19, 23, 29, 31])
 @pytest.mark.parametrize("it", [0, 2])
 def test_refine_step_bit_exact(eng_mode, scene_a, it, k):
     from oracle import oracle
@@ -164,15 +164,19 @@ def test_plane_sweep_k13_bit_exact_and_reference_golden(scene_d, mode):
         d, conf = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
         eng.set_sweep_tuning(tile_rows=5, planes_per_wave=3)              # several strips, several plane chunks
         d2, conf2 = eng.plane_sweep(ref, nbrs, depths, k, float(g["thresh"]))
-        d3, conf3 = eng.plane_sweep(ref, nbrs[:3], depths, 21, -0.2)       # the division form of the fast vote (run-time-k kernel)
+        d3, conf3 = eng.plane_sweep(ref, nbrs[:3], depths, 31, -0.2)       # the division form of the fast vote (run-time-k kernel)
+        d4, conf4 = eng.plane_sweep(ref, nbrs, depths, 25, 0.6)            # six sources at 25 x 25: a 128-bit validity history
     od, oc = scene_d.oracle_ctx(ref, nbrs, k, mode).plane_sweep(depths, float(g["thresh"]))
     _eq(d, od, f"{mode} depth")
     _eq(conf, oc, f"{mode} confidence")
     _eq(d2, od, f"{mode} depth (chunked)")
     _eq(conf2, oc, f"{mode} confidence (chunked)")
-    od3, oc3 = scene_d.oracle_ctx(ref, nbrs[:3], 21, mode).plane_sweep(depths, -0.2)
-    _eq(d3, od3, f"{mode} k21 depth")
-    _eq(conf3, oc3, f"{mode} k21 confidence")
+    od3, oc3 = scene_d.oracle_ctx(ref, nbrs[:3], 31, mode).plane_sweep(depths, -0.2)
+    _eq(d3, od3, f"{mode} k31 depth")
+    _eq(conf3, oc3, f"{mode} k31 confidence")
+    od4, oc4 = scene_d.oracle_ctx(ref, nbrs, 25, mode).plane_sweep(depths, 0.6)
+    _eq(d4, od4, f"{mode} k25 S6 depth")
+    _eq(conf4, oc4, f"{mode} k25 S6 confidence")
     assert np.mean(conf == g["confidence"]) > 0.995 and np.mean(d == g["depth_map"]) > 0.99
 
 
@@ -205,13 +209,15 @@ def test_ragged_shapes_and_float_images_bit_exact(shape, k, S):
         _eq(normal[0], on, f"{shape} k{k} normal (8-bit {quantise})")
 
 
+@pytest.mark.parametrize("k", [23, 29, 31])
 @pytest.mark.parametrize("mode", MODES)
-def test_largest_patch_with_six_sources(scene_d, mode):
+def test_largest_patch_with_six_sources(scene_d, mode, k):
     """k = 31 with S = 6: the largest LDS footprint of the run-time-k kernels (61.4 KB per wave for the sweep step,
-    63.3 KB for the plane sweep -- just under the 64 KB a workgroup may take): cost evaluation, a short sweep and the
-    plane sweep against the oracle."""
+    63.3 KB for the plane sweep -- just under the 64 KB a workgroup may take); k = 23 / 29 with S = 6: the compiled
+    kernels with the most register-resident rings and a validity history of 72 / 90 bits (a 128-bit integer): cost
+    evaluation, a short sweep and the plane sweep against the oracle."""
     from amvs.engine import make_pm_params
-    ref, srcs, k = 3, [0, 1, 2, 4, 5, 6], 31
+    ref, srcs = 3, [0, 1, 2, 4, 5, 6]
     depth = _mixed_depth(scene_d, ref, 3)
     depths = (1.0 / np.linspace(1 / scene_d.depth_max, 1 / scene_d.depth_min, 6)).astype(np.float32)
     with scene_d.engine(mode) as eng:
@@ -219,19 +225,19 @@ def test_largest_patch_with_six_sources(scene_d, mode):
         d, n, c = eng.patchmatch([ref], [srcs], make_pm_params(k, 1, 2, scene_d.depth_min, scene_d.depth_max), 4)
         sd, sc_ = eng.plane_sweep(ref, srcs, depths, k, 0.5)
     ctx = scene_d.oracle_ctx(ref, srcs, k, mode)
-    _eq(cost, ctx.patch_cost(depth), f"{mode} k31 S6 cost")
+    _eq(cost, ctx.patch_cost(depth), f"{mode} k{k} S6 cost")
     od, on, oc = ctx.patchmatch(1, 2, scene_d.depth_min, scene_d.depth_max, 4, ref)
-    _eq(d[0], od, f"{mode} k31 S6 depth")
-    _eq(n[0], on, f"{mode} k31 S6 normal")
-    _eq(c[0], oc, f"{mode} k31 S6 confidence")
+    _eq(d[0], od, f"{mode} k{k} S6 depth")
+    _eq(n[0], on, f"{mode} k{k} S6 normal")
+    _eq(c[0], oc, f"{mode} k{k} S6 confidence")
     osd, osc = ctx.plane_sweep(depths, 0.5)
-    _eq(sd, osd, f"{mode} k31 S6 sweep depth")
-    _eq(sc_, osc, f"{mode} k31 S6 sweep confidence")
+    _eq(sd, osd, f"{mode} k{k} S6 sweep depth")
+    _eq(sc_, osc, f"{mode} k{k} S6 sweep confidence")
 
 
-@pytest.mark.parametrize("patch", [13, 21])
+@pytest.mark.parametrize("patch", [13, 21, 31])
 def test_classes_accept_any_odd_patch_size(scene_b, capsys, patch):
-    """PatchMatchMVS(patch_size=13 / 21) / DenseStereoReconstructor(patch_size=13 / 21) run end to end (the
+    """PatchMatchMVS(patch_size=13 / 21 / 31) / DenseStereoReconstructor(patch_size=13 / 21 / 31) run end to end (the
     reference's constructors take any patch size); even and oversized patches are refused with a message."""
     import amvs
     from amvs._lib import AmvsError

@@ -34,7 +34,8 @@ def _engine(sc, mode="fast"):
 
 @pytest.mark.parametrize("k,S,H,W,n_ref", [(7, 4, 97, 131, 5), (3, 2, 40, 64, 1), (5, 3, 70, 200, 2),
                                            (9, 5, 64, 129, 3), (11, 6, 83, 190, 7), (7, 4, 150, 58, 4),
-                                           (13, 4, 60, 131, 3), (15, 3, 48, 104, 2), (19, 4, 50, 120, 2)])
+                                           (13, 4, 60, 131, 3), (15, 3, 48, 104, 2), (19, 4, 50, 120, 2),
+                                           (23, 6, 50, 120, 2)])
 def test_split_equals_fused(k, S, H, W, n_ref):
     sc = _u8_scene(max(n_ref, S + 1), H, W, 100 + k)
     ids = sorted(sc.poses)
@@ -58,7 +59,7 @@ def test_split_needs_fast_mode():
         with pytest.raises(amvs.AmvsError, match="fast mode only"):
             eng.patchmatch([0], [[1, 2, 3, 4]], p, 1)
     with _engine(sc, mode="fast") as eng:               # ... and a patch size the kernels are compiled for
-        p = make_pm_params(21, 1, 1, sc.depth_min, sc.depth_max, mode="fast", schedule="split")
+        p = make_pm_params(31, 1, 1, sc.depth_min, sc.depth_max, mode="fast", schedule="split")
         with pytest.raises(amvs.AmvsError, match="compiled patch sizes"):
             eng.patchmatch([0], [[1, 2, 3, 4]], p, 1)
 

@@ -34,7 +34,7 @@ def main():
     for case in range(args.cases):
         n = int(rng.integers(3, 8))
         H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
-        k = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23]))   # (21 and up: the run-time-k kernels)
+        k = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 27, 31]))   # (31: the run-time-k kernels)
         S = int(rng.integers(2, min(n - 1, 6) + 1))
         iters, samples = int(rng.integers(2, 4)), int(rng.integers(1, 4))
         mode = str(rng.choice(["fast", "exact"]))
@@ -84,7 +84,7 @@ def fuzz_sweep(args, rng, amvs, make_scene, oracle):
     for case in range(args.cases):
         n = int(rng.integers(3, 8))
         H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
-        k = int(rng.choice([3, 5, 7, 9, 11, 13, 17, 21]))
+        k = int(rng.choice([3, 5, 7, 9, 11, 13, 17, 21, 25, 31]))
         S = int(rng.integers(2, min(n - 1, 6) + 1))
         D = int(rng.integers(1, 40))
         mode = str(rng.choice(["fast", "exact"]))
