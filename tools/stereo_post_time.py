@@ -32,7 +32,7 @@ for rep in range(4):
     t.append(time.perf_counter())
     m0 = total
     if total > 500000:
-        chosen = np.random.choice(total, 500000, replace=False)
+        chosen = ds._draw_without_replacement(total, 500000)      # np.random.choice's draw, in kept buffers (the class)
         t.append(time.perf_counter())
         m0 = eng.cloud_take(chosen)
     else:
@@ -47,5 +47,5 @@ for rep in range(4):
     p, c = eng.fetch_cloud(m)
     t.append(time.perf_counter())
     d = [1e3 * (b - a) for a, b in zip(t, t[1:])]
-    print(f"rep {rep}: {total} raw points: backproject {d[0]:.1f} ms, np.random.choice {d[1]:.1f}, take {d[2]:.1f}, knn({m0}) {d[3]:.1f}, "
+    print(f"rep {rep}: {total} raw points: backproject {d[0]:.1f} ms, draw {d[1]:.1f}, take {d[2]:.1f}, knn({m0}) {d[3]:.1f}, "
           f"threshold {d[4]:.1f}, voxel {d[5]:.1f} -> {m}, fetch {d[6]:.1f}", flush=True)
